@@ -1,0 +1,296 @@
+"""Faiss-shaped surface over the gfx950 kNN library.
+
+Exactly the names the reference uses from ``faiss`` on its hot path
+(SURVEY.md 8b), so a maintainer can write
+``import image_search_engine_amd.faiss_compat as faiss`` in
+backend/utils.py:12, backend/engine.py:13, backend/indexer.py:9,
+backend/kmeans_faiss.py:1 and backend/siamese/test_index.py:
+
+    IndexFlatL2(d) / IndexFlatIP(d)      backend/utils.py:302,306
+    index.add(x) / .ntotal / .d          backend/utils.py:327-328, backend/engine.py:117
+    index.search(x, k) -> (D, I)         backend/engine.py:55, backend/kmeans_faiss.py:49
+    normalize_L2(x)                      backend/utils.py:303, backend/engine.py:53
+    write_index / read_index             backend/indexer.py:59, backend/engine.py:116
+    Kmeans(...).index / .centroids       backend/kmeans_faiss.py:29-44 (assignment only)
+
+All arithmetic runs on the MI355X through ``include/ise_knn.h``; there is no
+CPU path here.  Without the HIP library or without a GPU the constructors and
+``normalize_L2`` raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import struct
+import threading
+
+import numpy as np
+
+from . import _native as _n
+
+METRIC_INNER_PRODUCT = _n.METRIC_INNER_PRODUCT
+METRIC_L2 = _n.METRIC_L2
+
+_FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def _as_rows(x, d=None) -> np.ndarray:
+    """Coerce like the Faiss SWIG wrapper: C-contiguous float32 (n, d).
+    ``np.matrix`` (what ``.todense()`` yields, backend/engine.py:96) is accepted."""
+    x = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+    assert x.ndim == 2, "expected a 2-D array"
+    if d is not None:
+        assert x.shape[1] == d, f"dimension mismatch: got {x.shape[1]}, index has d={d}"
+    return x
+
+
+def _default_device() -> int:
+    import torch
+
+    return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+
+class IndexFlat:
+    """Exhaustive-search index owning a device copy of its rows.
+
+    Mirrors faiss.IndexFlat as the reference touches it: ``d``, ``ntotal``,
+    ``is_trained``, ``metric_type``, ``add``, ``search``, ``reset``,
+    ``reconstruct_n``.  Thread-safe for concurrent ``search`` callers (Flask
+    request threads, backend/engine.py:137; joblib threads,
+    backend/descriptors.py:125); the GIL is released while the device works.
+    """
+
+    def __init__(self, d: int, metric: int = METRIC_L2, device: int | None = None):
+        self.d = int(d)
+        self.metric_type = int(metric)
+        self.is_trained = True
+        self.device = _default_device() if device is None else int(device)
+        self._h = ctypes.c_void_p()
+        self._lock = threading.Lock()
+        _n.check(_n.lib.ise_index_create(ctypes.byref(self._h), self.d, self.metric_type, self.device))
+
+    # -- lifetime
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            _n.lib.ise_index_destroy(h)
+            h.value = None
+
+    @property
+    def ntotal(self) -> int:
+        n = ctypes.c_int64(0)
+        _n.check(_n.lib.ise_index_info(self._h, None, None, ctypes.byref(n), None))
+        return int(n.value)
+
+    def reset(self) -> None:
+        _n.check(_n.lib.ise_index_reset(self._h))
+
+    # -- build side
+    def add(self, x) -> None:
+        """Append rows (copied; the caller may mutate or free ``x`` afterwards)."""
+        x = _as_rows(x, self.d)
+        _n.check(_n.lib.ise_index_add_host(self._h, x.ctypes.data, x.shape[0]))
+
+    def add_torch(self, x) -> None:
+        """Append rows from a CUDA float32 tensor on this index's device (no host hop)."""
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == self.d
+        x = x.contiguous()
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        _n.check(_n.lib.ise_index_add_device(self._h, x.data_ptr(), x.shape[0], st))
+        torch.cuda.current_stream(x.device).synchronize()  # x may be freed by the caller
+
+    def reconstruct_n(self, i0: int = 0, n: int | None = None) -> np.ndarray:
+        n = self.ntotal - i0 if n is None else n
+        out = np.empty((n, self.d), dtype=np.float32)
+        _n.check(_n.lib.ise_index_reconstruct_host(self._h, i0, n, out.ctypes.data))
+        return out
+
+    # -- query side
+    def search(self, x, k: int):
+        """(D float32 (nq,k), I int64 (nq,k)), fresh arrays.  L2: squared distance
+        ascending; IP: descending; unfilled slots -1 / +-FLT_MAX."""
+        x = _as_rows(x, self.d)
+        k = int(k)
+        assert k > 0
+        nq = x.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _n.check(_n.lib.ise_index_search_host(self._h, x.ctypes.data, nq, k, D.ctypes.data, I.ctypes.data))
+        return D, I
+
+    def search_torch(self, xq, k: int):
+        """Device-resident search: CUDA float32 (nq,d) in, CUDA (D, I) out, enqueued on
+        the current torch stream (no host synchronisation)."""
+        import torch
+
+        assert xq.is_cuda and xq.dtype == torch.float32 and xq.dim() == 2 and xq.shape[1] == self.d
+        xq = xq.contiguous()
+        nq = xq.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+        st = torch.cuda.current_stream(xq.device).cuda_stream
+        with self._lock:
+            _n.check(_n.lib.ise_index_search_device(self._h, xq.data_ptr(), nq, int(k), D.data_ptr(),
+                                                    I.data_ptr(), st))
+        return D, I
+
+    def search_keys_torch(self, xq, k: int, id_base: int = 0):
+        """Shard-local search for the multi-GPU path: packed uint64 candidates
+        (as an int64 tensor (nq,k)), see include/ise_knn.h."""
+        import torch
+
+        assert xq.is_cuda and xq.dtype == torch.float32 and xq.dim() == 2 and xq.shape[1] == self.d
+        xq = xq.contiguous()
+        nq = xq.shape[0]
+        keys = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+        st = torch.cuda.current_stream(xq.device).cuda_stream
+        with self._lock:
+            _n.check(_n.lib.ise_index_search_keys_device(self._h, xq.data_ptr(), nq, int(k), int(id_base),
+                                                         keys.data_ptr(), st))
+        return keys
+
+    def search_timed_torch(self, xq, k: int, iters: int):
+        """bench.py hook: (D, I, scan_ms_avg, merge_ms_avg) with HIP events on the stream
+        the kernels run on."""
+        import torch
+
+        xq = xq.contiguous()
+        nq = xq.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+        st = torch.cuda.current_stream(xq.device).cuda_stream
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        with self._lock:
+            _n.check(_n.lib.ise_index_search_timed_device(self._h, xq.data_ptr(), nq, int(k), D.data_ptr(),
+                                                          I.data_ptr(), st, int(iters), ctypes.byref(a),
+                                                          ctypes.byref(b)))
+        return D, I, float(a.value), float(b.value)
+
+
+class IndexFlatL2(IndexFlat):
+    def __init__(self, d: int, device: int | None = None):
+        super().__init__(d, METRIC_L2, device)
+
+
+class IndexFlatIP(IndexFlat):
+    def __init__(self, d: int, device: int | None = None):
+        super().__init__(d, METRIC_INNER_PRODUCT, device)
+
+
+def merge_keys_torch(keys, metric: int):
+    """Merge all-gathered candidate lists: ``keys`` int64 CUDA (n_lists, nq, k) ->
+    (D float32 (nq,k), I int64 (nq,k)) on the same device."""
+    import torch
+
+    assert keys.is_cuda and keys.dtype == torch.int64 and keys.dim() == 3
+    keys = keys.contiguous()
+    n_lists, nq, k = keys.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=keys.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=keys.device)
+    st = torch.cuda.current_stream(keys.device).cuda_stream
+    _n.check(_n.lib.ise_merge_keys_device(keys.data_ptr(), n_lists, nq, k, int(metric), D.data_ptr(), I.data_ptr(),
+                                          keys.device.index, st))
+    return D, I
+
+
+def normalize_L2(x) -> None:
+    """In-place row L2 normalisation (faiss.normalize_L2): float32 C-contiguous (n, d)
+    required, returns None, zero rows untouched.  Runs on the GPU."""
+    import torch
+
+    if isinstance(x, torch.Tensor):
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        _n.check(_n.lib.ise_normalize_rows_device(x.data_ptr(), x.shape[0], x.shape[1], x.device.index, st))
+        return None
+    assert isinstance(x, np.ndarray) and x.dtype == np.float32 and x.ndim == 2 and x.flags.c_contiguous, \
+        "normalize_L2 needs a C-contiguous float32 (n, d) array"
+    _n.check(_n.lib.ise_normalize_rows_host(x.ctypes.data, x.shape[0], x.shape[1], _default_device()))
+    return None
+
+
+# ---------------------------------------------------------------- persistence
+# Faiss on-disk IndexFlat layout [upstream-faiss index_write.cpp, restated from
+# the published format; no sample .faiss file exists in the reference, so byte
+# compatibility with real Faiss files is UNPINNED]:
+#   fourcc "IxF2" (L2) / "IxFI" (IP); int32 d; int64 ntotal; int64 1<<20;
+#   int64 1<<20; uint8 is_trained; int32 metric_type; uint64 count (= N*d
+#   float32 words); count float32.
+_FOURCC = {METRIC_L2: b"IxF2", METRIC_INNER_PRODUCT: b"IxFI"}
+_HDR = struct.Struct("<4siqqqBi")
+
+
+def serialize_flat(d: int, metric: int, xb: np.ndarray) -> bytes:
+    xb = np.ascontiguousarray(xb, dtype="<f4")
+    n = xb.shape[0] if xb.size else 0
+    head = _HDR.pack(_FOURCC[metric], d, n, 1 << 20, 1 << 20, 1, metric)
+    return head + struct.pack("<Q", n * d) + xb.tobytes()
+
+
+def parse_flat(buf: bytes):
+    """-> (d, metric, xb float32 (n, d)); raises RuntimeError on a foreign file."""
+    if len(buf) < _HDR.size + 8:
+        raise RuntimeError("truncated index file")
+    fourcc, d, n, _, _, _, metric = _HDR.unpack_from(buf, 0)
+    if fourcc not in (b"IxF2", b"IxFI", b"IxFl"):
+        raise RuntimeError(f"unsupported index type {fourcc!r}: only flat indexes are readable")
+    if fourcc == b"IxF2":
+        metric = METRIC_L2
+    elif fourcc == b"IxFI":
+        metric = METRIC_INNER_PRODUCT
+    (count,) = struct.unpack_from("<Q", buf, _HDR.size)
+    if count != n * d or len(buf) < _HDR.size + 8 + 4 * count:
+        raise RuntimeError("corrupt flat index payload")
+    xb = np.frombuffer(buf, dtype="<f4", count=count, offset=_HDR.size + 8).reshape(n, d).astype(np.float32)
+    return d, metric, xb
+
+
+def write_index(index: IndexFlat, path) -> None:
+    with open(str(path), "wb") as f:
+        f.write(serialize_flat(index.d, index.metric_type, index.reconstruct_n(0, index.ntotal)))
+
+
+def read_index(path, device: int | None = None) -> IndexFlat:
+    with open(str(path), "rb") as f:
+        d, metric, xb = parse_flat(f.read())
+    index = IndexFlat(d, metric, device)
+    if xb.shape[0]:
+        index.add(xb)
+    return index
+
+
+class IndexIVFPQ:  # backend/utils.py:323 ("cell-probe"): approximate, out of scope
+    def __init__(self, *a, **kw):
+        raise NotImplementedError("IndexIVFPQ ('cell-probe') is outside the exact brute-force hot path")
+
+
+class Kmeans:
+    """Holder for the nearest-centroid assignment the reference does through
+    ``faiss.Kmeans(...).index.search(X, 1)`` (backend/kmeans_faiss.py:29-50).
+    ``spherical=True`` there makes ``.index`` an inner-product index over
+    unit-norm centroids [upstream-faiss].  Only assignment is on the scoped
+    path: ``train`` accepts ``init_centroids`` (the "loaded from a file" case,
+    backend/kmeans_faiss.py:40-41) and builds ``.index`` from them; Lloyd
+    iterations are a "next" row."""
+
+    def __init__(self, d, k, niter=25, nredo=1, seed=1234, spherical=False, verbose=False, **_):
+        self.d, self.k = int(d), int(k)
+        self.niter, self.nredo, self.seed = niter, nredo, seed
+        self.spherical, self.verbose = spherical, verbose
+        self.centroids = None
+        self.index = None
+        self.obj = np.zeros(0, dtype=np.float32)
+
+    def train(self, x, init_centroids=None):
+        if init_centroids is None:
+            raise NotImplementedError("k-means training is not on the scoped hot path; pass init_centroids")
+        c = _as_rows(init_centroids, self.d).copy()
+        assert c.shape[0] == self.k
+        if self.spherical:
+            normalize_L2(c)
+        self.centroids = c
+        self.index = IndexFlatIP(self.d) if self.spherical else IndexFlatL2(self.d)
+        self.index.add(c)
+        self.obj = np.zeros(1, dtype=np.float32)
+        return 0.0

@@ -1,0 +1,117 @@
+/*
+ * include/ise_knn.h -- C ABI of the MI355X (gfx950) brute-force kNN library.
+ *
+ * This is the drop-in boundary for the one hot path of
+ * ManuelZ/image-search-engine: the arithmetic the reference delegates to the
+ * Faiss IndexFlat objects.  The reference has no FFI of its own (pure Python
+ * over the Faiss SWIG module), so every entry point names the
+ * reference call site whose native work it replaces.  Plain pointers and
+ * sizes only; no C++ or torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (ISE_E_*); nothing
+ *     throws across the ABI; ise_last_error() returns a thread-local message.
+ *   - the caller owns every buffer it passes; the index owns a private copy of
+ *     added rows (reference contract of index.add, backend/utils.py:327).
+ *   - "device" pointers are HIP device pointers on the index's device;
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     *_device entry points only enqueue work; *_host entry points block.
+ *   - distances follow Faiss: METRIC_L2 = SQUARED L2, ascending;
+ *     METRIC_INNER_PRODUCT = inner product, descending; ties by ascending id;
+ *     a row enters a result only if strictly better than +-FLT_MAX, so
+ *     unfilled slots come back as id -1 / distance +-FLT_MAX.
+ *   - ids are row numbers in insertion order (+ id_base); a (sharded) index
+ *     holds fewer than 2^32 rows.
+ *   - concurrent *_host calls on one handle are safe (serialised per handle);
+ *     *_device calls on one handle must be issued from one thread at a time
+ *     and onto one stream at a time (they share the handle's workspace).
+ */
+#ifndef ISE_KNN_H
+#define ISE_KNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISE_METRIC_INNER_PRODUCT 0 /* faiss.METRIC_INNER_PRODUCT */
+#define ISE_METRIC_L2 1            /* faiss.METRIC_L2 */
+
+#define ISE_OK 0
+#define ISE_E_INVALID -1  /* bad argument (shape, k, NULL) */
+#define ISE_E_HIP -2      /* HIP runtime error (message has the hipError string) */
+#define ISE_E_NOMEM -3    /* host or device allocation failed */
+#define ISE_E_NODEVICE -4 /* no usable gfx950 device */
+
+#define ISE_MAX_K 2048 /* largest k accepted by the search entry points */
+
+typedef struct ise_index ise_index_t;
+
+/* library / device ------------------------------------------------------- */
+int ise_version(void);
+const char* ise_last_error(void);
+int ise_device_count(int* count);
+/* name of device `device` into buf (NUL-terminated), e.g. "gfx950:sramecc+:xnack-" */
+int ise_device_arch(int device, char* buf, int buflen);
+
+/* index lifetime: replaces faiss.IndexFlatL2(d) / faiss.IndexFlatIP(d)
+ * (backend/utils.py:302,306; backend/siamese/siamese_pt/create_index.py:40). */
+int ise_index_create(ise_index_t** out, int d, int metric, int device);
+int ise_index_destroy(ise_index_t* h);
+int ise_index_reset(ise_index_t* h); /* drop all rows, keep d/metric */
+int ise_index_info(const ise_index_t* h, int* d, int* metric, int64_t* ntotal, int* device);
+
+/* index.add(x) (backend/utils.py:327): append n rows of d float32, copied.
+ * Also computes the per-row squared norms the L2 search uses. */
+int ise_index_add_host(ise_index_t* h, const float* x, int64_t n);
+int ise_index_add_device(ise_index_t* h, const float* x_dev, int64_t n, void* stream);
+
+/* copy rows [i0, i0+n) back to host as n x d float32 (used by write_index,
+ * backend/indexer.py:59). */
+int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n, float* out);
+
+/* index.search(x, k) -> (D, I) (backend/engine.py:55,
+ * backend/siamese/test_index.py:54, backend/kmeans_faiss.py:49).
+ * q: nq x d float32; D: nq x k float32; I: nq x k int64. */
+int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq, int k,
+                          float* D, int64_t* I);
+int ise_index_search_device(ise_index_t* h, const float* q_dev, int64_t nq, int k,
+                            float* D_dev, int64_t* I_dev, void* stream);
+
+/* Shard-local search for the multi-GPU path: writes nq x k
+ * packed candidates, sorted best-first, suitable for one all-gather:
+ *   key = (order-preserving uint32 image of the score) << 32 | (row + id_base)
+ * with unfilled slots = 0xFFFFFFFFFFFFFFFF.  For inner product the score
+ * image is taken of -score so that ascending key order is best-first for
+ * both metrics. */
+int ise_index_search_keys_device(ise_index_t* h, const float* q_dev, int64_t nq, int k,
+                                 uint32_t id_base, uint64_t* keys_dev, void* stream);
+
+/* Merge n_lists sorted candidate lists per query (layout [n_lists][nq][k],
+ * e.g. the all-gathered output of ise_index_search_keys_device over ranks)
+ * into D (nq x k float32) and I (nq x k int64).  Needs no index handle;
+ * `device` selects the GPU the pointers live on. */
+int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int64_t nq, int k,
+                          int metric, float* D_dev, int64_t* I_dev, int device, void* stream);
+
+/* faiss.normalize_L2(x) (backend/utils.py:303, backend/engine.py:53,
+ * backend/siamese/test_index.py:53, siamese_pt/create_index.py:57,
+ * siamese_tf/create_index.py:54):
+ * in-place row L2 normalisation of n x d float32, zero rows untouched. */
+int ise_normalize_rows_device(float* x_dev, int64_t n, int d, int device, void* stream);
+int ise_normalize_rows_host(float* x, int64_t n, int d, int device);
+
+/* measurement hook for bench.py: run the scan + merge kernels of one search
+ * batch `iters` times on `stream` and return the average scan-kernel and
+ * merge-kernel durations in milliseconds, measured with hipEvents recorded on
+ * that stream around each kernel.  Results land in D_dev / I_dev as for
+ * ise_index_search_device. */
+int ise_index_search_timed_device(ise_index_t* h, const float* q_dev, int64_t nq, int k,
+                                  float* D_dev, int64_t* I_dev, void* stream, int iters,
+                                  float* scan_ms_avg, float* merge_ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISE_KNN_H */

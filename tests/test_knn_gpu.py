@@ -1,0 +1,313 @@
+"""GPU parity tests: HIP kNN (through the C ABI) vs the CPU oracle.
+Run on the MI355X box with:  python -m pytest tests -m gpu
+Parity is UNPINNED with respect to a real Faiss build (see oracle/knn_oracle.py):
+the expected values come from the exact float64 oracle and the committed
+golden fixtures it generated."""
+import glob
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import knn_oracle as ko
+from tests.knn_checks import assert_knn_matches
+
+pytestmark = pytest.mark.gpu
+
+L2, IP = ko.METRIC_L2, ko.METRIC_INNER_PRODUCT
+
+
+@pytest.fixture(scope="module")
+def faiss():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import image_search_engine_amd.faiss_compat as fc
+
+    return fc
+
+
+def make_index(faiss, metric, d):
+    return faiss.IndexFlatL2(d) if metric == L2 else faiss.IndexFlatIP(d)
+
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = [g for g in GOLDEN if not os.path.basename(g).startswith("normalize")]
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
+def test_golden_fixture(faiss, path):
+    z = np.load(path)
+    xb, xq, k, metric = z["xb"], z["xq"], int(z["k"]), int(z["metric"])
+    index = make_index(faiss, metric, xb.shape[1])
+    index.add(xb)
+    assert index.ntotal == xb.shape[0]
+    D, I = index.search(xq, k)
+    n_mism = assert_knn_matches(D, I, z["D"], z["I"], xb, xq, metric, gap=z["gap"])
+    if (z["gap"] == 0).all() or (z["gap"] > 1e-4).all():
+        assert n_mism == 0
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("n,d,nq,k", [
+    (10_000, 128, 16, 5),     # BASELINE config 1 shape
+    (5_000, 512, 7, 10),
+    (20_000, 64, 40, 20),     # 3 query tiles, k = NUM_IMAGES_TO_RETURN
+    (3_000, 2048, 3, 10),     # ResNet-50 flatten width (backend/descriptors.py:166-168)
+    (1_001, 48, 1, 32),       # ragged row count, one query, k at the single-pass limit
+    (4_097, 96, 17, 1),       # k = 1
+])
+def test_random_vs_oracle(faiss, metric, n, d, nq, k):
+    rng = np.random.default_rng(n + d + nq + k + metric)
+    xb = rng.random((n, d), dtype=np.float32)
+    xq = rng.random((nq, d), dtype=np.float32)
+    index = make_index(faiss, metric, d)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, metric)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, metric, gap=ko.kth_gap(xb, xq, k, metric))
+
+
+@pytest.mark.parametrize("k", [33, 64, 100, 257])
+def test_large_k_multipass(faiss, k):
+    rng = np.random.default_rng(k)
+    xb = rng.random((3000, 40), dtype=np.float32)
+    xq = rng.random((5, 40), dtype=np.float32)
+    index = faiss.IndexFlatL2(40)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2)
+
+
+def test_against_c_restatement(faiss):
+    """The float32 C restatement of Faiss's small-batch algorithm agrees too."""
+    from oracle import flat_oracle as fo
+
+    rng = np.random.default_rng(5)
+    xb = rng.random((8000, 128), dtype=np.float32)
+    xq = rng.random((9, 128), dtype=np.float32)
+    for metric in (L2, IP):
+        index = make_index(faiss, metric, 128)
+        index.add(xb)
+        D, I = index.search(xq, 10)
+        Dc, Ic, _ = fo.knn_flat(xb, xq, 10, metric)
+        assert_knn_matches(D, I, Dc, Ic, xb, xq, metric)
+
+
+def test_incremental_add_and_reset(faiss):
+    rng = np.random.default_rng(11)
+    xb = rng.random((1500, 100), dtype=np.float32)
+    xq = rng.random((4, 100), dtype=np.float32)
+    index = faiss.IndexFlatL2(100)
+    for lo, hi in ((0, 1), (1, 700), (700, 1500)):
+        index.add(xb[lo:hi])
+    assert index.ntotal == 1500
+    D, I = index.search(xq, 8)
+    D_ref, I_ref = ko.knn_exact(xb, xq, 8, L2)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2)
+    assert np.array_equal(index.reconstruct_n(0, 1500), xb)
+    index.reset()
+    assert index.ntotal == 0
+    D, I = index.search(xq, 3)
+    assert (I == -1).all() and (D == np.finfo(np.float32).max).all()
+
+
+def test_add_copies_and_matrix_input(faiss):
+    rng = np.random.default_rng(3)
+    xb = rng.random((300, 20), dtype=np.float32)
+    keep = xb.copy()
+    index = faiss.IndexFlatL2(20)
+    index.add(np.matrix(xb))  # np.matrix accepted (backend/engine.py:96 passes .todense())
+    xb[:] = 0  # the index owns its copy
+    xq = np.matrix(rng.random((2, 20), dtype=np.float32))
+    D, I = index.search(xq, 4)
+    D_ref, I_ref = ko.knn_exact(keep, np.asarray(xq), 4, L2)
+    assert_knn_matches(D, I, D_ref, I_ref, keep, np.asarray(xq, dtype=np.float32), L2)
+
+
+def test_shape_errors(faiss):
+    index = faiss.IndexFlatL2(16)
+    with pytest.raises(AssertionError):
+        index.add(np.zeros((3, 15), np.float32))
+    index.add(np.zeros((3, 16), np.float32))
+    with pytest.raises(AssertionError):
+        index.search(np.zeros((1, 17), np.float32), 2)
+    with pytest.raises(AssertionError):
+        index.search(np.zeros((1, 16), np.float32), 0)
+    with pytest.raises(RuntimeError):
+        index.search(np.zeros((1, 16), np.float32), 5000)
+
+
+def test_nan_and_inf_rows_never_returned(faiss):
+    rng = np.random.default_rng(8)
+    xb = rng.random((50, 16), dtype=np.float32)
+    xb[7, 3] = np.nan
+    xb[9, 0] = np.inf
+    xq = rng.random((2, 16), dtype=np.float32)
+    for metric in (L2, IP):
+        index = make_index(faiss, metric, 16)
+        index.add(xb)
+        D, I = index.search(xq, 50)
+        D_ref, I_ref = ko.knn_exact(xb, xq, 50, metric)
+        # NaN scores never enter; an L2 distance of inf never enters; an inner product
+        # of +inf does (it is strictly better than -FLT_MAX), as in Faiss's heap
+        assert 7 not in I and (I[:, -1] == -1).all()
+        assert np.array_equal(I < 0, I_ref < 0)
+        for q in range(2):
+            assert sorted(I[q].tolist()) == sorted(I_ref[q].tolist())
+
+
+def test_normalize_L2(faiss, golden_dir):
+    z = np.load(os.path.join(golden_dir, "normalize_n9_d100.npz"))
+    x = z["x"].copy()
+    assert faiss.normalize_L2(x) is None
+    assert np.array_equal(x[3], np.zeros(100, np.float32))  # zero row untouched
+    np.testing.assert_allclose(x, z["y"], rtol=2e-6, atol=1e-7)
+    from oracle import flat_oracle as fo
+
+    y = z["x"].copy()
+    fo.renorm_L2(y)
+    np.testing.assert_allclose(x, y, rtol=2e-6, atol=1e-7)
+    with pytest.raises(AssertionError):
+        faiss.normalize_L2(z["x"].astype(np.float64))
+
+
+def test_cosine_is_ip_on_normalised(faiss):
+    """create_search_index('cosine') semantics (backend/utils.py:300-303)."""
+    rng = np.random.default_rng(21)
+    xb = rng.standard_normal((2000, 128)).astype(np.float32)
+    xq = rng.standard_normal((5, 128)).astype(np.float32)
+    faiss.normalize_L2(xb)
+    faiss.normalize_L2(xq)
+    index = faiss.IndexFlatIP(128)
+    index.add(xb)
+    D, I = index.search(xq, 9)
+    D_ref, I_ref = ko.knn_exact(xb, xq, 9, IP)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, IP)
+    assert (D <= 1.0 + 1e-5).all()
+
+
+def test_write_read_roundtrip(faiss, tmp_path):
+    rng = np.random.default_rng(2)
+    xb = rng.random((777, 33), dtype=np.float32)
+    xq = rng.random((3, 33), dtype=np.float32)
+    for metric in (L2, IP):
+        index = make_index(faiss, metric, 33)
+        index.add(xb)
+        p = tmp_path / f"idx{metric}.faiss"
+        faiss.write_index(index, str(p))
+        back = faiss.read_index(str(p))
+        assert (back.d, back.ntotal, back.metric_type) == (33, 777, metric)
+        D0, I0 = index.search(xq, 6)
+        D1, I1 = back.search(xq, 6)
+        assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+
+
+def test_concurrent_search_threads(faiss):
+    """Flask request threads may enter index.search concurrently (backend/engine.py:137)."""
+    rng = np.random.default_rng(4)
+    xb = rng.random((20000, 64), dtype=np.float32)
+    index = faiss.IndexFlatL2(64)
+    index.add(xb)
+    qs = [rng.random((3, 64), dtype=np.float32) for _ in range(8)]
+    refs = [ko.knn_exact(xb, q, 5, L2) for q in qs]
+    out = [None] * 8
+
+    def work(i):
+        for _ in range(5):
+            out[i] = index.search(qs[i], 5)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(8):
+        assert_knn_matches(out[i][0], out[i][1], refs[i][0], refs[i][1], xb, qs[i], L2)
+
+
+def test_torch_device_api_and_determinism(faiss):
+    import torch
+
+    rng = np.random.default_rng(6)
+    xb = rng.random((30000, 256), dtype=np.float32)
+    xq = rng.random((16, 256), dtype=np.float32)
+    index = faiss.IndexFlatL2(256)
+    index.add_torch(torch.from_numpy(xb).cuda())
+    tq = torch.from_numpy(xq).cuda()
+    D1, I1 = index.search_torch(tq, 10)
+    D2, I2 = index.search_torch(tq, 10)
+    torch.cuda.synchronize()
+    assert torch.equal(I1, I2) and torch.equal(D1, D2)  # bitwise reproducible
+    D_ref, I_ref = ko.knn_exact(xb, xq, 10, L2)
+    assert_knn_matches(D1.cpu().numpy(), I1.cpu().numpy(), D_ref, I_ref, xb, xq, L2)
+    Dh, Ih = index.search(xq, 10)
+    assert np.array_equal(Ih, I1.cpu().numpy()) and np.array_equal(Dh, D1.cpu().numpy())
+
+
+def test_shard_keys_merge_equals_unsharded(faiss):
+    """Row shards + packed-key merge == one index, single process."""
+    import torch
+
+    rng = np.random.default_rng(9)
+    xb = rng.random((12345, 96), dtype=np.float32)
+    xq = rng.random((20, 96), dtype=np.float32)
+    tq = torch.from_numpy(xq).cuda()
+    for metric in (L2, IP):
+        whole = make_index(faiss, metric, 96)
+        whole.add(xb)
+        D0, I0 = whole.search(xq, 10)
+        keys = []
+        G = 4
+        for r in range(G):
+            lo, hi = 12345 * r // G, 12345 * (r + 1) // G
+            sh = make_index(faiss, metric, 96)
+            sh.add(xb[lo:hi])
+            keys.append(sh.search_keys_torch(tq, 10, id_base=lo))
+        D1, I1 = faiss.merge_keys_torch(torch.stack(keys), metric)
+        assert np.array_equal(I0, I1.cpu().numpy())
+        assert np.array_equal(D0, D1.cpu().numpy())
+
+
+def test_full_size_properties(faiss):
+    """BASELINE size (1M x 512, k = 10): size-independent properties instead of a
+    full oracle pass: planted duplicates of the queries come back first at distance
+    ~0, results are sorted, ids unique, and a 2-shard merge reproduces them."""
+    import torch
+
+    n, d, nq, k = 1_000_000, 512, 16, 10
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    xb = torch.rand((n, d), generator=g, device="cuda", dtype=torch.float32)
+    xq = torch.rand((nq, d), generator=g, device="cuda", dtype=torch.float32)
+    plant = torch.arange(nq, device="cuda") * 60_001 + 17
+    xb[plant] = xq
+    index = faiss.IndexFlatL2(d)
+    index.add_torch(xb)
+    D, I = index.search_torch(xq, k)
+    torch.cuda.synchronize()
+    Dn, In = D.cpu().numpy(), I.cpu().numpy()
+    assert np.array_equal(In[:, 0], plant.cpu().numpy())
+    assert (Dn[:, 0] <= 1e-3).all()
+    assert (np.diff(Dn, axis=1) >= 0).all()
+    assert all(len(set(r)) == k for r in In.tolist())
+    # exact check of the reported distances against float64 on the returned rows
+    rows = xb[I.reshape(-1)].double().reshape(nq, k, d)
+    ref = ((rows - xq.double()[:, None, :]) ** 2).sum(-1).cpu().numpy()
+    assert (np.abs(Dn - ref) <= 1e-4 * np.maximum(1, ref)).all()
+    # every other row is no closer than the k-th (checked on a strided sample in float64)
+    samp = xb[::97].double()
+    ds = torch.cdist(xq.double(), samp).pow(2).cpu().numpy()
+    kth = ref[:, -1:] * (1 + 1e-6)
+    ids = np.arange(0, n, 97)
+    for q in range(nq):
+        closer = ids[ds[q] < ref[q, -1] * (1 - 1e-6)]
+        assert set(closer.tolist()) <= set(In[q].tolist())
+    del samp, ds, kth
+    # two shards + merge
+    half = n // 2
+    a, b = faiss.IndexFlatL2(d), faiss.IndexFlatL2(d)
+    a.add_torch(xb[:half])
+    b.add_torch(xb[half:])
+    keys = torch.stack([a.search_keys_torch(xq, k, 0), b.search_keys_torch(xq, k, half)])
+    D2, I2 = faiss.merge_keys_torch(keys, L2)
+    assert torch.equal(I2, I) and torch.equal(D2, D)
