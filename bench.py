@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec of exact brute-force L2 kNN, 1M x 512 fp32, k=10.
+
+  python bench.py --gpus 1 --steps K --warmup W            (default)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one search batch of --nq queries (default 16, the HBM-bound headline
+batch of SURVEY.md 8d) against the whole index, inputs resident in HBM.  With N
+GPUs the 1M rows are row-sharded (strong scaling) and a step also contains the
+one all-gather + merge.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def make_inputs(n, d, nq, lo, hi):
+    """BASELINE.md section 4 inputs; only rows [lo, hi) are materialised."""
+    rng = np.random.default_rng(1234)
+    out = np.empty((hi - lo, d), dtype=np.float32)
+    step = 1 << 16
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        blk = rng.random((e - s, d), dtype=np.float32)
+        a, b = max(s, lo), min(e, hi)
+        if a < b:
+            out[a - lo: b - lo] = blk[a - s: b - s]
+        if e >= hi:
+            break
+    xq = np.random.default_rng(4321).random((nq, d), dtype=np.float32)
+    return out, xq
+
+
+def host_cores():
+    """Threads this process may really run: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def pmc_traffic(n, d, nq, k, world):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/): counters cannot be read from inside the timed process."""
+    path = os.path.join(ROOT, "profiles", "r01", f"bench_nq{nq}_hbm_pmc.json")
+    if world != 1 or (n, d, k) != (1_000_000, 512, 10) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["scan_kernel"]["traffic_bytes_per_launch"]
+
+
+def cpu_baseline(xb, xq, k, budget_s=12.0):
+    """Faiss-equivalent CPU restatement (oracle/flat_oracle.c, kind 'port') timed on this
+    host's cores on a bounded sample: the same query batch against the first `rows` index
+    rows, repeated until ~budget_s of CPU work; QPS is scaled to the full index."""
+    from oracle import flat_oracle as fo
+
+    fo.build()
+    cores = min(fo.max_threads(), host_cores())
+    n = xb.shape[0]
+    rows = min(n, 250_000)
+    sample = np.ascontiguousarray(xb[:rows])
+    fo.knn_flat(sample[:1000], xq, k, 1, cores)  # warm the thread pool
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        D, I, nt = fo.knn_flat(sample, xq, k, 1, cores)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 50:
+            break
+    per_batch = el / reps * (n / rows)
+    return {
+        "value": xq.shape[0] / per_batch,
+        "unit": "queries/s",
+        "cores": int(nt),
+        "kind": "port",
+        "sample": f"nq={xq.shape[0]} batch vs first {rows} of {n} rows x{reps} reps, scaled by {n / rows:.1f} "
+                  f"(oracle/flat_oracle.c: Faiss small-batch scan restated, {nt} OpenMP threads)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=512)
+    ap.add_argument("--nq", type=int, default=16)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import image_search_engine_amd.faiss_compat as faiss
+
+    n, d, nq, k = args.n, args.d, args.nq, args.k
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    xb_host, xq_host = make_inputs(n, d, nq, lo, hi)
+    xq = torch.from_numpy(xq_host).to(dev)
+
+    if world > 1:
+        import torch.distributed as dist
+        from image_search_engine_amd.sharded import ShardedIndexFlat
+
+        dist.init_process_group("nccl", device_id=dev)
+        index = ShardedIndexFlat(d, faiss.METRIC_L2)
+        index.add_local(torch.from_numpy(xb_host).to(dev))
+        local = index.backend.index
+
+        def run(steps):
+            # depth-1 pipeline: the all-gather of batch i overlaps the scan of batch i+1
+            out = None
+            ticket = index.search_begin(xq, k)
+            for _ in range(steps - 1):
+                nxt = index.search_begin(xq, k)
+                out = index.search_end(ticket)
+                ticket = nxt
+            out = index.search_end(ticket)
+            return out
+
+        def barrier():
+            dist.barrier()
+    else:
+        index = faiss.IndexFlatL2(d)
+        index.add_torch(torch.from_numpy(xb_host).to(dev))
+        local = index
+
+        def run(steps):
+            out = None
+            for _ in range(steps):
+                out = index.search_torch(xq, k)
+            return out
+
+        def barrier():
+            pass
+
+    run(max(1, args.warmup))
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    D, I = run(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # roofline of the dominant kernel (the shard-local scan), timed with HIP events on
+    # the stream it runs on, inside the library
+    n_local = hi - lo
+    _, _, scan_ms, merge_ms = local.search_timed_torch(xq, k, 50)
+    alg_bytes = 4.0 * n_local * d + 4.0 * nq * d + 12.0 * nq * k
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        res = {
+            "metric": "queries/sec, exact brute-force L2 kNN (recall@10 vs exact CPU), 1Mx512 fp32 index, k=10",
+            "value": nq * args.steps / el,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{n}x{d} fp32 uniform[0,1) index (default_rng 1234), L2, k={k}, "
+                                   f"nq={nq} queries per step, index resident in HBM"
+                                   + (f", row-sharded over {world} GPUs, one all-gather + merge per step" if world > 1 else ""),
+                       "n": n, "d": d, "k": k, "nq": nq},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, d, nq, k, world),
+                         "kernel": "scan_kernel", "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
+                         "algorithmic_bytes": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(xb_host, xq_host, k)
+            res["cpu_baseline"] = cb
+            # parity gate on the benchmark data itself: full-index CPU pass for the same batch
+            from oracle import flat_oracle as fo
+
+            Dc, Ic, _ = fo.knn_flat(xb_host, xq_host, k, 1, cb["cores"])
+            In, Dn = I.cpu().numpy(), D.cpu().numpy()
+            res["recall_at_k"] = float(np.mean([len(set(In[q]) & set(Ic[q])) / k for q in range(nq)]))
+            res["ids_identical"] = bool(np.array_equal(In, Ic))
+            res["max_abs_dist_err"] = float(np.abs(Dn - Dc).max())
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
