@@ -111,6 +111,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # rehearsal knobs (one-GPU box): ISE_BENCH_SHARE_GPU=1 puts every rank on cuda:0,
+    # ISE_BENCH_BACKEND=gloo swaps RCCL for gloo; the driver's runs use neither
+    if os.environ.get("ISE_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -125,7 +129,11 @@ def main():
         import torch.distributed as dist
         from image_search_engine_amd.sharded import ShardedIndexFlat
 
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ISE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         index = ShardedIndexFlat(d, faiss.METRIC_L2)
         index.add_local(torch.from_numpy(xb_host).to(dev))
         local = index.backend.index
@@ -142,7 +150,10 @@ def main():
             return out
 
         def barrier():
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
     else:
         index = faiss.IndexFlatL2(d)
         index.add_torch(torch.from_numpy(xb_host).to(dev))

@@ -15,7 +15,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libise_knn.so")
+# $ISE_KNN_LIB selects a dev build of the same library (e.g. csrc/libise_knn_ablate.so)
+LIB_PATH = os.environ.get("ISE_KNN_LIB") or os.path.join(_HERE, "csrc", "libise_knn.so")
 
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1

@@ -108,107 +108,283 @@ struct ScanParams {
     int nq, k, metric;
     uint32_t id_base;
     int tiles_total, tiles_per_block;
+    int ablate;  // dev builds (-DISE_ABLATE): bit mask of phases to skip, from $ISE_ABLATE
+    unsigned long long* stamps;  // dev builds: [blocks][waves][8] s_memrealtime stamps (100 MHz), or null
 };
+#ifdef ISE_ABLATE
+#define ABL(bit) (p.ablate & (bit))
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        if (p.stamps && lane == 0)                                                                 \
+            p.stamps[((size_t)blockIdx.x * W + w) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+#else
+#define ABL(bit) 0
+#define STAMP(i) do {} while (0)
+#endif
 
-// CAP: per-(wave, query) LDS candidate capacity (>= 2k, <= 64)
+#define TAU0 ((u64)0xFF7FFFFFu << 32) /* ord(FLT_MAX) << 32: strict gate score < FLT_MAX */
+#define KB 32                          /* boot-winner slots per query = largest k of one pass */
+
+// Wave-level selection: the min(k, #real) smallest of the keys held as
+// kk[e] = element (lane + 64 e), e < KPL (KEY_PAD = empty slot; elements with
+// 64 e >= n must be empty), written SORTED to dst[0..).  Returns the number
+// written; *kth = the k-th smallest key when k were written.
+// Quickselect on the key value with wave-uniform control flow (ballot counts),
+// then an all-pairs rank among the <= k winners only.  Real keys are unique and
+// lie strictly between 0 and KEY_PAD.
+template <int KPL>
+__device__ __forceinline__ int wave_select(const u64 (&kk)[KPL], int n, int k, u64* dst, u64* kth) {
+    int nreal = 0;
+#pragma unroll
+    for (int e = 0; e < KPL; e++)
+        if (64 * e < n) nreal += __popcll(__ballot(kk[e] != KEY_PAD));
+    u64 kstar = KEY_PAD - 1;  // fewer than k real keys: all of them win
+    if (nreal > k) {
+        u64 L = 0, H = KEY_PAD;  // the target lies in the open interval (L, H)
+        int t = k - 1;           // its rank among the keys of that interval
+        for (int round = 0;; round++) {
+            // pivot: an element of the interval, position rotated per round so that
+            // sorted input does not degrade the search
+            u64 P = 0;
+            bool found = false;
+            const int rot = (round * 23 + 7) & 63;
+#pragma unroll
+            for (int e = 0; e < KPL; e++) {
+                if (64 * e < n && !found) {
+                    const u64 m = __ballot(kk[e] > L && kk[e] < H);
+                    if (m) {
+                        const u64 hi = (m >> rot) << rot;
+                        const int pick = __ffsll((long long)(hi ? hi : m)) - 1;
+                        P = readlane_u64(kk[e], pick);
+                        found = true;
+                    }
+                }
+            }
+            int c_lt = 0;
+#pragma unroll
+            for (int e = 0; e < KPL; e++)
+                if (64 * e < n) c_lt += __popcll(__ballot(kk[e] > L && kk[e] < P));
+            if (c_lt == t) {
+                kstar = P;
+                break;
+            }
+            if (c_lt > t) {
+                H = P;
+            } else {
+                L = P;
+                t -= c_lt + 1;
+            }
+        }
+    }
+    // rank among the winners (keys <= kstar); at most k of them
+    int rk[KPL];
+#pragma unroll
+    for (int e = 0; e < KPL; e++) rk[e] = 0;
+#pragma unroll
+    for (int es = 0; es < KPL; es++) {
+        if (64 * es < n) {
+            u64 m = __ballot(kk[es] <= kstar);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const u64 ki = readlane_u64(kk[es], l);
+#pragma unroll
+                for (int e = 0; e < KPL; e++) rk[e] += (ki < kk[e]) ? 1 : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < KPL; e++)
+        if (64 * e < n && kk[e] <= kstar) dst[rk[e]] = kk[e];
+    const int nw = min(nreal, k);
+    if (nw == k) *kth = kstar;
+    return nw;
+}
+
+// LDS bytes of one scan block (host mirror: scan_lds_bytes)
+#define CAP 16 /* slots of a wave's private candidate list; merged out at MERGE_TRIG */
+#define MERGE_TRIG 8
+__host__ __device__ constexpr size_t scan_lds_layout(int S, int waves) {
+    return (size_t)(QT * S + QT) * 4      /* qs, xn */
+           + (size_t)QT * 8               /* tauS */
+           + (size_t)QT * 4 * 2           /* bwc, lockS */
+           + (size_t)waves * QT * 4       /* cntS */
+           + (size_t)QT * KB * 8          /* bootw */
+           + (size_t)waves * QT * CAP * 8 /* cand (boot staging aliases it: 16 x W*16 keys) */;
+}
+
 // CH : k-steps (16 floats each) per register chunk; dp/16 is a multiple of CH
-// W  : waves per block (8, or 4 when the query tile leaves less LDS)
-template <int CAP, int CH, int W>
+// W  : waves per block
+//
+// Top-k bookkeeping (all off the streaming path):
+//   boot   every wave scores its first tile and dumps all 16x16 keys; two block
+//          barriers later each query has the sorted k best of those W*16 rows
+//          (bootw) and a block-wide threshold tauS[q] = their k-th key.
+//   steady a lane holds 4 scores per tile for one query and compares them with
+//          its copy of the threshold; survivors (a few per wave over the whole
+//          kernel) are appended to the wave's private list; at MERGE_TRIG entries
+//          the wave takes the query's LDS lock, folds its list into bootw and
+//          publishes the new k-th key, so tauS tracks the block's running k-th best.
+//   final  per query, one wave selects the top-k of bootw + what is left in the W
+//          private lists and writes the block's sorted list.
+template <int CH, int W>
 __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p) {
-    constexpr int WAVES_PER_BLOCK = W;
     constexpr int BLOCK_THREADS = W * 64;
+    constexpr int TPR = BLOCK_THREADS / QT;       // threads staging one query row
+    constexpr int KPLB = (W * 16 + 63) / 64;      // boot: keys per lane
+    constexpr int KPLF = (KB + W * CAP + 63) / 64;  // final: keys per lane (worst case)
+    static_assert(KB + CAP <= 64 && MERGE_TRIG + 4 <= CAP && W * 16 * 16 <= W * QT * CAP, "list sizes");
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int KPL = (CAP + 63) / 64;  // keys per lane in a compaction
     const int S = p.qs_stride;
-    float* qs = reinterpret_cast<float*>(smem);      // [16][S]
-    float* xn = qs + QT * S;                         // [16]
-    int* cntS = reinterpret_cast<int*>(xn + QT);     // [waves][16]
-    u64* cand = reinterpret_cast<u64*>(cntS + WAVES_PER_BLOCK * QT);  // [waves][16][CAP]
+    float* qs = reinterpret_cast<float*>(smem);                 // [16][S]
+    float* xn = qs + QT * S;                                    // [16]
+    u64* tauS = reinterpret_cast<u64*>(xn + QT);                // [16]
+    int* bwc = reinterpret_cast<int*>(tauS + QT);               // [16]
+    int* lockS = bwc + QT;                                      // [16]
+    int* cntS = lockS + QT;                                     // [W][16]
+    u64* bootw = reinterpret_cast<u64*>(cntS + W * QT);         // [16][KB]
+    u64* cand = bootw + QT * KB;                                // [W][16][CAP]
+    u64* boot = cand;                                           // [16][W*16], dead before cand is used
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.y * QT;
     const int nqt = min(QT, p.nq - q0);
     const int k = p.k;
-
-    // ---- stage the query tile (zero padded to 16 x dp) and its norms
-    for (int cc = 0; cc < QT; cc++) {
-        const float* src = p.q + (size_t)(q0 + cc) * p.d;
-        for (int j = tid; j < S; j += BLOCK_THREADS)
-            qs[cc * S + j] = (cc < nqt && j < p.d) ? src[j] : 0.f;
-    }
-    __syncthreads();
-    for (int cc = w; cc < QT; cc += WAVES_PER_BLOCK) {
-        float s = 0.f;
-        for (int j = lane; j < p.dp; j += 64) {
-            const float v = qs[cc * S + j];
-            s = fmaf(v, v, s);
-        }
-        s = wave_sum_f32(s);
-        if (lane == 0) xn[cc] = s;
-    }
-    __syncthreads();
-
-    const float xq_n = xn[c];
-    const float* qrow = qs + c * S + 4 * g;
     const int nsteps = p.dp >> 4;
     const int t0 = blockIdx.x * p.tiles_per_block;
     const int t1 = min(t0 + p.tiles_per_block, p.tiles_total);
     const bool l2 = p.metric == ISE_METRIC_L2;
+
+    auto load_chunk = [&](f32x4(&a)[CH], int tile, int s0) {
+        const float* base = p.xb + ((size_t)tile * 16 + c) * p.dp + 4 * g + 16 * s0;
+#pragma unroll
+        for (int s = 0; s < CH; s++) a[s] = *reinterpret_cast<const f32x4*>(base + 16 * s);
+    };
+    auto load_norms = [&](int tile) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(p.norms + (size_t)tile * 16 + 4 * g);
+    };
+
+    STAMP(0);
+    // ---- the first index chunk is requested before anything else: its HBM
+    // latency overlaps the query staging below
+    int tile = t0 + w;
+    const bool has_work = tile < t1 && !ABL(16);
+    f32x4 a0[CH], a1[CH];
+    f32x4 yn_cur = {0.f, 0.f, 0.f, 0.f};
+    if (has_work) {
+        load_chunk(a0, tile, 0);
+        yn_cur = load_norms(tile);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- stage the query tile (zero padded to 16 x S) and |x|^2: TPR threads per row
+    {
+        const int cc = tid / TPR, t = tid % TPR;
+        const bool rowok = cc < nqt && !ABL(1);
+        const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
+        float sn = 0.f;
+        if ((p.d & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.q) & 15) == 0)) {
+            const int d4 = p.d >> 2, S4 = S >> 2;
+            for (int j4 = t; j4 < S4; j4 += TPR) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rowok && j4 < d4) v = *reinterpret_cast<const f32x4*>(src + 4 * j4);
+                *reinterpret_cast<f32x4*>(qs + cc * S + 4 * j4) = v;
+                sn = fmaf(v[0], v[0], sn);
+                sn = fmaf(v[1], v[1], sn);
+                sn = fmaf(v[2], v[2], sn);
+                sn = fmaf(v[3], v[3], sn);
+            }
+        } else {
+            for (int j = t; j < S; j += TPR) {
+                const float v = (rowok && j < p.d) ? src[j] : 0.f;
+                qs[cc * S + j] = v;
+                sn = fmaf(v, v, sn);
+            }
+        }
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) sn += __shfl_xor(sn, o);
+        if (t == 0) xn[cc] = sn;
+        if (tid < QT) {
+            tauS[tid] = TAU0;
+            bwc[tid] = 0;
+            lockS[tid] = 0;
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+
+    const float xq_n = xn[c];
+    const float* qrow = qs + c * S + 4 * g;
     const u64 qmask = 0x0001000100010001ull << c;
     const u64 lt_mask = (1ull << lane) - 1ull;
     const u64 key_floor = (p.floor_keys && c < nqt) ? p.floor_keys[q0 + c] : 0ull;
     const bool use_floor = p.floor_keys != nullptr;
 
-    u64 tau = (u64)ord_f32(FLT_MAX) << 32;  // strict gate: score < FLT_MAX
+    u64 tau = TAU0;
     int cnt = 0;
+    bool booted = false;
     u64* mybuf = cand + (size_t)(w * QT + c) * CAP;
 
-    // keep the k best of query qq's buffer (sorted, at the front), refresh tau
-    auto compact = [&](int qq) {
-        wave_lds_fence();
+    // fold the wave's private list of query qq into the block's sorted list bootw[qq]
+    // (top-k of their union) under the query's LDS lock; publish the new k-th key
+    auto merge_out = [&](int qq) {
         const int n_ = __builtin_amdgcn_readlane(cnt, qq);
-        u64* buf = cand + (size_t)(w * QT + qq) * CAP;
-        u64 kk[KPL];
-        int rk[KPL];
-#pragma unroll
-        for (int e = 0; e < KPL; e++) {
-            const int idx = lane + 64 * e;
-            kk[e] = idx < n_ ? buf[idx] : KEY_PAD;
-            rk[e] = 0;
-        }
-        for (int i = 0; i < n_; i++) {
-            u64 ki;
-            if (KPL == 1 || i < 64) ki = readlane_u64(kk[0], i & 63);
-            else ki = readlane_u64(kk[KPL - 1], i & 63);
-#pragma unroll
-            for (int e = 0; e < KPL; e++) rk[e] += (ki < kk[e]) ? 1 : 0;
-        }
+        const u64* buf = cand + (size_t)(w * QT + qq) * CAP;
+        if (lane == 0)
+            while (atomicCAS(&lockS[qq], 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+        wave_lds_fence();
+        const int nb = bwc[qq];
+        u64 kk[1];
+        kk[0] = lane < nb ? bootw[qq * KB + lane] : (lane - nb < n_ ? buf[lane - nb] : KEY_PAD);
         wave_lds_fence();
         u64 ktau = KEY_PAD;
-#pragma unroll
-        for (int e = 0; e < KPL; e++) {
-            const bool valid = (lane + 64 * e) < n_;
-            if (valid && rk[e] < k) buf[rk[e]] = kk[e];
-            const u64 hit = __ballot(valid && rk[e] == k - 1);
-            if (hit) ktau = readlane_u64(kk[e], __ffsll((long long)hit) - 1);
-        }
-        if (c == qq) {
-            cnt = min(n_, k);
-            if (n_ >= k) tau = ktau;
+        const int nw = wave_select<1>(kk, nb + n_, k, bootw + qq * KB, &ktau);  // nb + n_ <= KB + CAP <= 64
+        if (lane == 0) {
+            bwc[qq] = nw;
+            if (nw == k) tauS[qq] = ktau;  // <= the old value: the union only adds keys
         }
         wave_lds_fence();
+        if (lane == 0) atomicExch(&lockS[qq], 0);
+        if (c == qq) {
+            cnt = 0;
+            if (nw == k) tau = min_u64(tau, ktau);
+        }
+    };
+
+    // boot: all W*16 first-tile keys of a query -> its k best + the block threshold
+    auto boot_phase = [&](const u64(&key)[4]) {
+        STAMP(2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) boot[(size_t)c * (W * 16) + w * 16 + 4 * g + j] = key[j];
+        __syncthreads();
+        for (int qq = w; qq < QT; qq += W) {
+            u64 kk[KPLB];
+#pragma unroll
+            for (int e = 0; e < KPLB; e++)
+                kk[e] = (lane + 64 * e) < W * 16 ? boot[(size_t)qq * (W * 16) + lane + 64 * e] : KEY_PAD;
+            u64 ktau = TAU0;
+            const int nw = wave_select<KPLB>(kk, W * 16, k, bootw + qq * KB, &ktau);
+            if (lane == 0) {
+                bwc[qq] = nw;
+                tauS[qq] = ktau;
+            }
+        }
+        __syncthreads();
+        tau = tauS[c];
+        booted = true;
+        STAMP(3);
     };
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 
-    auto epilogue = [&](int tile, f32x4 yn) {
+    auto epilogue = [&](int etile, f32x4 yn) {
         const f32x4 dot = acc0 + acc1;
         acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const long long row0 = (long long)tile * 16 + 4 * g;
+        const long long row0 = (long long)etile * 16 + 4 * g;
         u64 key[4];
-        bool pend = false;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float sc;
@@ -219,12 +395,17 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
                 sc = -dot[j];
             }
             bool ok = (row0 + j < p.n) && (sc < FLT_MAX) && (c < nqt);
-            u64 kj = ((u64)ord_f32(sc) << 32) | (uint32_t)((uint32_t)(row0 + j) + p.id_base);
+            const u64 kj = ((u64)ord_f32(sc) << 32) | (uint32_t)((uint32_t)(row0 + j) + p.id_base);
             if (use_floor) ok = ok && (kj > key_floor);
             key[j] = ok ? kj : KEY_PAD;
-            pend = pend || (key[j] < tau);
         }
-        if (__any(pend)) {
+        if (!booted) {
+            boot_phase(key);
+            return;
+        }
+        tau = min_u64(tau, tauS[c]);
+        const bool pend = key[0] < tau || key[1] < tau || key[2] < tau || key[3] < tau;
+        if (__any(pend) && !ABL(2)) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const bool v = key[j] < tau;
@@ -233,22 +414,17 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
                     const u64 mq = m & qmask;
                     if (v) mybuf[cnt + __popcll(mq & lt_mask)] = key[j];
                     cnt += __popcll(mq);
-                    u64 nm = __ballot(cnt > CAP - 4) & 0xFFFFull;
+                    u64 nm = __ballot(cnt >= MERGE_TRIG) & 0xFFFFull;
                     while (nm) {
                         const int qq = __ffsll((long long)nm) - 1;
                         nm &= nm - 1;
-                        compact(qq);
+                        merge_out(qq);
                     }
                 }
             }
         }
     };
 
-    auto load_chunk = [&](f32x4(&a)[CH], int tile, int s0) {
-        const float* base = p.xb + ((size_t)tile * 16 + c) * p.dp + 4 * g + 16 * s0;
-#pragma unroll
-        for (int s = 0; s < CH; s++) a[s] = *reinterpret_cast<const f32x4*>(base + 16 * s);
-    };
     auto compute_chunk = [&](const f32x4(&a)[CH], int s0) {
 #pragma unroll
         for (int s = 0; s < CH; s++) {
@@ -259,23 +435,16 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], b[3], acc1, 0, 0, 0);
         }
     };
-    auto load_norms = [&](int tile) -> f32x4 {
-        return *reinterpret_cast<const f32x4*>(p.norms + (size_t)tile * 16 + 4 * g);
-    };
 
     // ---- main loop: two register chunks in flight, tiles interleaved by wave.
     // Loads are issued unconditionally (the last iteration re-reads its own
     // chunk) so that no control-flow join sits between a load and its use:
     // hipcc then emits counted vmcnt waits and the prefetch stays in flight.
-    int tile = t0 + w;
-    if (tile < t1) {
-        f32x4 a0[CH], a1[CH];
-        f32x4 yn_cur = load_norms(tile);
+    if (has_work) {
         int s0 = 0;
-        load_chunk(a0, tile, 0);
         for (;;) {
             int ns0 = s0 + CH, ntile = tile;
-            if (ns0 >= nsteps) { ns0 = 0; ntile = tile + WAVES_PER_BLOCK; }
+            if (ns0 >= nsteps) { ns0 = 0; ntile = tile + W; }
             bool has_next = ntile < t1;
             {
                 const int lt = has_next ? ntile : tile, ls = has_next ? ns0 : s0;
@@ -283,14 +452,14 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
                 const f32x4 yn_nx = load_norms(lt);
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs
                 compute_chunk(a0, s0);
-                if (s0 + CH >= nsteps) epilogue(tile, yn_cur);
+                if (s0 + CH >= nsteps && !ABL(8)) epilogue(tile, yn_cur);
                 yn_cur = yn_nx;
             }
             if (!has_next) break;
             tile = ntile; s0 = ns0;
 
             ns0 = s0 + CH; ntile = tile;
-            if (ns0 >= nsteps) { ns0 = 0; ntile = tile + WAVES_PER_BLOCK; }
+            if (ns0 >= nsteps) { ns0 = 0; ntile = tile + W; }
             has_next = ntile < t1;
             {
                 const int lt = has_next ? ntile : tile, ls = has_next ? ns0 : s0;
@@ -298,38 +467,49 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
                 const f32x4 yn_nx = load_norms(lt);
                 __builtin_amdgcn_sched_barrier(0);
                 compute_chunk(a1, s0);
-                if (s0 + CH >= nsteps) epilogue(tile, yn_cur);
+                if (s0 + CH >= nsteps && !ABL(8)) epilogue(tile, yn_cur);
                 yn_cur = yn_nx;
             }
             if (!has_next) break;
             tile = ntile; s0 = ns0;
         }
     }
+    if (!booted) {  // a wave without a tile still takes part in the two boot barriers
+        const u64 none[4] = {KEY_PAD, KEY_PAD, KEY_PAD, KEY_PAD};
+        boot_phase(none);
+    }
 
-    // ---- flush: every (wave, query) list sorted, at most k long
-    for (int qq = 0; qq < QT; qq++) compact(qq);
+    // ---- final: per query, rank bootw + the W private lists, write the sorted top-k
+    STAMP(4);
     if (g == 0) cntS[w * QT + c] = cnt;
     __syncthreads();
-
-    // ---- block merge: wave w merges the 8 per-wave lists of queries w, w+8
-    for (int qq = w; qq < QT; qq += WAVES_PER_BLOCK) {
-        const int li = lane < WAVES_PER_BLOCK ? lane : 0;
-        const int n_i = lane < WAVES_PER_BLOCK ? cntS[li * QT + qq] : 0;
-        const u64* lst = cand + (size_t)(li * QT + qq) * CAP;
-        int pos = 0;
-        u64 cur = pos < n_i ? lst[0] : KEY_PAD;
-        u64 res = KEY_PAD;
-        for (int r = 0; r < k; r++) {
-            const u64 m = readlane_u64(row_min_u64(cur), 0);  // lanes 0..7 live in row 0
-            if (lane == r) res = m;
-            if (cur == m && m != KEY_PAD) {
-                pos++;
-                cur = pos < n_i ? lst[pos] : KEY_PAD;
+    STAMP(5);
+    for (int qq = w; qq < QT && !ABL(4); qq += W) {
+        int P[W + 2];
+        P[0] = 0;
+        P[1] = bwc[qq];
+#pragma unroll
+        for (int i = 0; i < W; i++) P[i + 2] = P[i + 1] + cntS[i * QT + qq];
+        const int n = P[W + 1];
+        u64 kk[KPLF];
+#pragma unroll
+        for (int e = 0; e < KPLF; e++) {
+            kk[e] = KEY_PAD;
+            const int idx = lane + 64 * e;
+            if (64 * e < n) {
+                if (idx < P[1]) kk[e] = bootw[qq * KB + idx];
+#pragma unroll
+                for (int i = 0; i < W; i++)
+                    if (idx >= P[i + 1] && idx < P[i + 2])
+                        kk[e] = cand[(size_t)(i * QT + qq) * CAP + idx - P[i + 1]];
             }
         }
         u64* out = p.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * QT + qq) * k;
-        if (lane < k) out[lane] = res;
+        u64 kth_unused;
+        const int nw = wave_select<KPLF>(kk, n, k, out, &kth_unused);
+        if (lane >= nw && lane < k) out[lane] = KEY_PAD;  // k <= KB <= 64
     }
+    STAMP(6);
 }
 
 // ---------------------------------------------------------------- merge kernel
@@ -509,10 +689,7 @@ static int qs_stride_for(int dp) {
     return dp + pad;
 }
 #define KPASS_MAX 32 /* largest k one scan pass selects; larger k runs floor-keyed passes */
-static int cap_for_k(int k) { return k <= 16 ? 32 : 64; }
-static size_t scan_lds_bytes(int dp, int cap, int waves) {
-    return (size_t)(QT * qs_stride_for(dp) + QT) * 4 + (size_t)waves * QT * 4 + (size_t)waves * QT * cap * 8;
-}
+static size_t scan_lds_bytes(int dp, int waves) { return scan_lds_layout(qs_stride_for(dp), waves); }
 
 extern "C" int ise_version(void) { return 100; }
 extern "C" const char* ise_last_error(void) { return g_err.c_str(); }
@@ -742,54 +919,58 @@ extern "C" int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n,
 
 // ---- search
 #define LDS_LIMIT (160 * 1024)
-template <int CAP, int CH, int W>
+template <int CH, int W>
 static void launch_one(dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     static bool attr_done = false;  // benign race: the attribute is idempotent
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CAP, CH, W>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CH, W>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr_done = true;
     }
-    hipLaunchKernelGGL((scan_kernel<CAP, CH, W>), grid, dim3(W * 64), lds, st, sp);
+    hipLaunchKernelGGL((scan_kernel<CH, W>), grid, dim3(W * 64), lds, st, sp);
 }
-template <int CAP, int W>
+template <int W>
 static void launch_scan_ch(int ch, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     switch (ch) {
-        case 8: launch_one<CAP, 8, W>(grid, lds, st, sp); break;
-        case 4: launch_one<CAP, 4, W>(grid, lds, st, sp); break;
-        case 2: launch_one<CAP, 2, W>(grid, lds, st, sp); break;
-        default: launch_one<CAP, 1, W>(grid, lds, st, sp); break;
+        case 8: launch_one<8, W>(grid, lds, st, sp); break;
+        case 4: launch_one<4, W>(grid, lds, st, sp); break;
+        case 2: launch_one<2, W>(grid, lds, st, sp); break;
+        default: launch_one<1, W>(grid, lds, st, sp); break;
     }
 }
-static void launch_scan(int cap, int ch, int waves, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
-    if (cap == 32) {
-        if (waves == 8) launch_scan_ch<32, 8>(ch, grid, lds, st, sp);
-        else launch_scan_ch<32, 4>(ch, grid, lds, st, sp);
-    } else {
-        if (waves == 8) launch_scan_ch<64, 8>(ch, grid, lds, st, sp);
-        else launch_scan_ch<64, 4>(ch, grid, lds, st, sp);
-    }
+static void launch_scan(int ch, int waves, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
+    if (waves == 8) launch_scan_ch<8>(ch, grid, lds, st, sp);
+    else launch_scan_ch<4>(ch, grid, lds, st, sp);
 }
 
 struct ScanPlan {
-    int nblocks, tiles_total, tiles_per_block, nqt, cap, ch, kpass, waves;
+    int nblocks, tiles_total, tiles_per_block, nqt, ch, kpass, waves;
     size_t lds;
 };
 
 static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     pl->kpass = k < KPASS_MAX ? k : KPASS_MAX;
-    pl->cap = cap_for_k(pl->kpass);
     pl->ch = chunk_steps(h->dp);
     pl->waves = 8;
-    pl->lds = scan_lds_bytes(h->dp, pl->cap, 8);
+    pl->lds = scan_lds_bytes(h->dp, 8);
     if (pl->lds > LDS_LIMIT) {
         pl->waves = 4;
-        pl->lds = scan_lds_bytes(h->dp, pl->cap, 4);
+        pl->lds = scan_lds_bytes(h->dp, 4);
     }
     if (pl->lds > LDS_LIMIT)
         return fail(ISE_E_INVALID, "d too large: the 16-query tile must fit the 160 KiB LDS (d <= 2048)");
     pl->tiles_total = (int)((h->n + 15) / 16);
-    const int blocks_per_cu = pl->lds <= LDS_LIMIT / 2 ? 2 : 1;
+    int blocks_per_cu = pl->lds <= LDS_LIMIT / 2 ? 2 : 1;
+#ifdef ISE_ABLATE
+    if (const char* e = getenv("ISE_PLAN")) {  // dev: "waves,blocks_per_cu"
+        int wv = 8, bpc = 2;
+        if (sscanf(e, "%d,%d", &wv, &bpc) == 2 && (wv == 4 || wv == 8) && bpc >= 1) {
+            pl->waves = wv;
+            pl->lds = scan_lds_bytes(h->dp, wv);
+            blocks_per_cu = bpc;
+        }
+    }
+#endif
     int nb = h->num_cu * blocks_per_cu;
     const int max_useful = (pl->tiles_total + pl->waves - 1) / pl->waves;
     if (nb > max_useful) nb = max_useful;
@@ -871,6 +1052,12 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     sp.n = h->n; sp.d = h->d; sp.dp = h->dp; sp.qs_stride = qs_stride_for(h->dp);
     sp.nq = (int)nq; sp.k = pl.kpass; sp.metric = h->metric; sp.id_base = id_base;
     sp.tiles_total = pl.tiles_total; sp.tiles_per_block = pl.tiles_per_block;
+    sp.ablate = 0;
+    sp.stamps = nullptr;
+#ifdef ISE_ABLATE
+    if (const char* e = getenv("ISE_ABLATE")) sp.ablate = atoi(e);
+    if (const char* e = getenv("ISE_STAMPS")) sp.stamps = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
 
     MergeParams mp;
     mp.lists = h->part; mp.stride_list = (long long)QT * pl.kpass;
@@ -881,7 +1068,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     if (k <= pl.kpass) {
         mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out;
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
-        launch_scan(pl.cap, pl.ch, pl.waves, grid, pl.lds, st, sp);
+        launch_scan(pl.ch, pl.waves, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
@@ -897,7 +1084,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     for (int off = 0; off < k; off += pl.kpass) {
         sp.floor_keys = off ? floor_dev : nullptr;
         mp.D = nullptr; mp.I = nullptr; mp.keys_out = pass_keys;
-        launch_scan(pl.cap, pl.ch, pl.waves, grid, pl.lds, st, sp);
+        launch_scan(pl.ch, pl.waves, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
         HIP_TRY(hipGetLastError());

@@ -1,0 +1,114 @@
+"""CPU tests: the oracle against the committed golden vectors and against its own
+independent restatements (float64 exact, float32 C small-batch, float32 BLAS-form)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import flat_oracle as fo
+from oracle import knn_oracle as ko
+from tests import keycodec as kc
+from tests.knn_checks import assert_knn_matches
+
+L2, IP = ko.METRIC_L2, ko.METRIC_INNER_PRODUCT
+GOLDEN = sorted(g for g in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(g).startswith("normalize"))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
+def test_numpy_oracle_reproduces_golden(path):
+    z = np.load(path)
+    D, I = ko.knn_exact(z["xb"], z["xq"], int(z["k"]), int(z["metric"]))
+    assert np.array_equal(I, z["I"]) and np.array_equal(D, z["D"])
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
+def test_c_restatement_matches_golden(path):
+    z = np.load(path)
+    xb, xq, k, metric = z["xb"], z["xq"], int(z["k"]), int(z["metric"])
+    for nthreads in (0, 3):  # Faiss's own per-query scheme, and the slab-split one
+        D, I, _ = fo.knn_flat(xb, xq, k, metric, nthreads)
+        assert_knn_matches(D, I, z["D"], z["I"], xb, xq, metric, gap=z["gap"])
+
+
+def test_blas_form_matches_exact():
+    rng = np.random.default_rng(1)
+    xb = rng.random((5000, 64), dtype=np.float32)
+    xq = rng.random((33, 64), dtype=np.float32)
+    for metric in (L2, IP):
+        D, I = ko.knn_blas_f32(xb, xq, 10, metric)
+        Dr, Ir = ko.knn_exact(xb, xq, 10, metric)
+        assert_knn_matches(D, I, Dr, Ir, xb, xq, metric, gap=ko.kth_gap(xb, xq, 10, metric))
+
+
+def test_dict_branch_semantics():
+    """backend/siamese/test_index.py:58-69: normalise, per-row Euclidean distance,
+    ascending argsort.  Same ranking as squared L2; values are its square root."""
+    rng = np.random.default_rng(2)
+    index = rng.standard_normal((300, 128))
+    index /= np.linalg.norm(index, axis=1, keepdims=True)  # create_index.py:62-85 (float64 unit rows)
+    emb = rng.standard_normal((1, 128))
+    emb = emb / np.linalg.norm(emb)
+    dist = np.array([np.linalg.norm(index[i, :] - emb) for i in range(len(index))])
+    order = dist.argsort()[:9]
+    D, I = ko.knn_exact(index.astype(np.float32), emb.astype(np.float32), 9, L2)
+    assert np.array_equal(I[0], order)
+    np.testing.assert_allclose(np.sqrt(D[0]), dist[order], rtol=1e-5)
+
+
+def test_strict_gate_and_padding():
+    xb = np.array([[0.0], [np.nan], [np.inf], [3e38]], np.float32)
+    xq = np.array([[0.0]], np.float32)
+    D, I = ko.knn_exact(xb, xq, 4, L2)  # (3e38)^2 = inf in f32 -> >= FLT_MAX, never enters
+    assert I.tolist() == [[0, -1, -1, -1]] and D[0, 1] == ko.FLT_MAX
+    Dc, Ic, _ = fo.knn_flat(xb, xq, 4, L2)
+    assert np.array_equal(Ic, I) and np.array_equal(Dc, D)
+    D, I = ko.knn_exact(np.zeros((0, 4), np.float32), np.zeros((2, 4), np.float32), 3, IP)
+    assert (I == -1).all() and (D == -ko.FLT_MAX).all()
+
+
+def test_normalize_oracles_agree(golden_dir):
+    z = np.load(os.path.join(golden_dir, "normalize_n9_d100.npz"))
+    assert np.array_equal(ko.normalize_rows(z["x"]), z["y"])
+    y = z["x"].copy()
+    fo.renorm_L2(y)
+    np.testing.assert_allclose(y, z["y"], rtol=2e-6, atol=1e-7)
+    assert np.array_equal(y[3], np.zeros(100, np.float32))
+    np.testing.assert_allclose(np.linalg.norm(np.delete(y, 3, 0), axis=1), 1.0, rtol=1e-6)
+
+
+def test_assignment_ip_equals_l2_on_unit_centroids(golden_dir):
+    a = np.load(os.path.join(golden_dir, "assign_ip_n512_c256_d128.npz"))
+    b = np.load(os.path.join(golden_dir, "assign_l2_n512_c256_d128.npz"))
+    assert np.array_equal(a["I"], b["I"])  # quirk 5.9-7: arg-max IP == arg-min L2 for unit centroids
+    assert np.array_equal(ko.assign_nearest(a["xb"], a["xb"], IP).ravel(), np.arange(256))
+
+
+def test_shard_merge_equals_unsharded():
+    rng = np.random.default_rng(3)
+    xb = rng.random((999, 24), dtype=np.float32)
+    xb[500] = xb[10]  # cross-shard duplicate: the tie must resolve to the lower global id
+    xq = np.concatenate([rng.random((4, 24), dtype=np.float32), xb[10:11]])
+    for metric in (L2, IP):
+        Dp, Ip = [], []
+        for r in range(5):
+            lo, hi = 999 * r // 5, 999 * (r + 1) // 5
+            d_, i_ = ko.knn_exact(xb[lo:hi], xq, 7, metric, id_offset=lo)
+            Dp.append(d_)
+            Ip.append(i_)
+        D, I = ko.merge_shards(Dp, Ip, 7, metric)
+        Dr, Ir = ko.knn_exact(xb, xq, 7, metric)
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+        # the packed-key image of the same merge (what travels in the all-gather)
+        keys = np.stack([kc.encode(d_, i_, metric) for d_, i_ in zip(Dp, Ip)])  # (G, nq, k)
+        merged = np.sort(keys.transpose(1, 0, 2).reshape(len(xq), -1), axis=1)[:, :7]
+        Dk, Ik = kc.decode(merged, metric)
+        assert np.array_equal(Ik, Ir) and np.array_equal(Dk, Dr)
+
+
+def test_key_codec_is_order_preserving():
+    v = np.array([-np.inf, -3e38, -1.5, -0.0, 0.0, 1e-30, 2.0, 3e38, np.inf], np.float32)
+    o = kc.ord_f32(v).astype(np.int64)
+    assert (np.diff(o) >= 0).all() and (np.diff(o)[[0, 1, 2, 4, 5, 6, 7]] > 0).all()
+    assert np.array_equal(kc.unord_f32(kc.ord_f32(v)).view(np.uint32), v.view(np.uint32))

@@ -1,0 +1,117 @@
+"""CPU tests of the N > 1 path: world_size-2 `gloo` process groups drive the real
+ShardedIndexFlat host logic (row partition, id bases, packed-key all-gather,
+begin/end pipelining).  The shard-local compute is a TEST DOUBLE built on the
+oracle (the product backend is HIP-only and needs a GPU); the packed-key format
+it speaks is the one include/ise_knn.h defines."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleShardBackend:
+    """Test double for HipShardBackend: same interface, oracle arithmetic."""
+
+    def __init__(self, d, metric):
+        from oracle import knn_oracle as ko
+
+        self.ko, self.d, self.metric = ko, d, metric
+        self.xb = np.zeros((0, d), np.float32)
+        self.device = torch.device("cpu")
+
+    @property
+    def ntotal(self):
+        return self.xb.shape[0]
+
+    def add(self, x):
+        x = x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        self.xb = np.concatenate([self.xb, x.astype(np.float32)])
+
+    def local_search_keys(self, xq, k, id_base):
+        from tests import keycodec as kc
+
+        D, I = self.ko.knn_exact(self.xb, xq.numpy(), k, self.metric, id_offset=id_base)
+        return torch.from_numpy(kc.encode(D, I, self.metric).view(np.int64))
+
+    def merge(self, keys_all):
+        from tests import keycodec as kc
+
+        g, nq, k = keys_all.shape
+        keys = keys_all.numpy().view(np.uint64).transpose(1, 0, 2).reshape(nq, g * k)
+        D, I = kc.decode(np.sort(keys, axis=1)[:, :k], self.metric)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+
+def _worker(rank, world, port, metric, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from image_search_engine_amd.sharded import ShardedIndexFlat
+        from oracle import knn_oracle as ko
+
+        rng = np.random.default_rng(7)
+        d, k = 24, 6
+        xb = rng.random((n, d), dtype=np.float32)
+        if n > 40:
+            xb[n - 3] = xb[2]  # duplicate across shards: tie must go to the lower global id
+        xq = np.concatenate([rng.random((4, d), dtype=np.float32), xb[2:3]]) if n > 2 else \
+            rng.random((3, d), dtype=np.float32)
+        idx = ShardedIndexFlat(d, metric, backend=OracleShardBackend(d, metric))
+        idx.add_global(xb)
+        lo, hi = ShardedIndexFlat.shard_bounds(n, world, rank)
+        assert idx.backend.ntotal == hi - lo and idx.id_base == lo and idx.ntotal == n
+        tq = torch.from_numpy(xq)
+        D, I = idx.search(tq, k)
+        Dr, Ir = ko.knn_exact(xb, xq, k, metric)
+        assert np.array_equal(I.numpy(), Ir), (rank, I, Ir)
+        assert np.array_equal(D.numpy(), Dr)
+        # pipelined form: two batches in flight, results unchanged and in order
+        t1 = idx.search_begin(tq, k)
+        t2 = idx.search_begin(tq[:2], k)
+        D1, I1 = idx.search_end(t1)
+        D2, I2 = idx.search_end(t2)
+        assert np.array_equal(I1.numpy(), Ir) and np.array_equal(I2.numpy(), Ir[:2])
+        # every rank holds the same answer
+        allI = [torch.empty_like(I) for _ in range(world)]
+        dist.all_gather(allI, I)
+        assert all(torch.equal(allI[0], t) for t in allI)
+        with pytest.raises(RuntimeError):
+            idx.add_global(xb)  # append-once: ids stay contiguous per rank
+        q.put((rank, "ok"))
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("n", [1001, 3])
+def test_world2_gloo_sharded_search_equals_unsharded(metric, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, metric, n, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
