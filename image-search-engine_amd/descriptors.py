@@ -1,0 +1,211 @@
+"""Feature extraction with the reference's surface (backend/descriptors.py:24-204):
+``SupportsDescribe``, ``Describer``, ``describe_dataset``, ``CNNDescriptor``.
+
+What changes under the surface: the CNN runs BATCHED on PyTorch-ROCm (the
+reference does one image per forward pass and one host<->device round trip per
+image, backend/descriptors.py:185-196) and preprocessing (resize 224, ImageNet
+normalise, HWC->CHW) runs on the device.  What is kept deliberately:
+  * images are BGR uint8 and go into the RGB-trained normalisation unswapped
+    (quirk 5.9-1: backend/descriptors.py:65,153-159,185);
+  * ``describe(image)`` returns a flat CPU float32 tensor of 2048 values
+    (backend/descriptors.py:196);
+  * per-image failures are printed and skipped (backend/descriptors.py:94-96).
+cv2 / albumentations / torchvision are not in this image: decoding uses PIL, the
+resize is ``F.interpolate(bilinear, align_corners=False)`` on float pixels, which
+differs from cv2's 11-bit fixed-point uint8 resize by <= 1 LSB before normalisation
+(semantic, not bit, parity for preprocessing).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Protocol
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .config import Config, DnnModels
+from .resnet import resnet50_features
+from .utils import chunkIt
+
+config = Config()
+
+_MEAN = (0.485, 0.456, 0.406)  # albumentations A.Normalize() defaults (ImageNet)
+_STD = (0.229, 0.224, 0.225)
+
+
+class SupportsDescribe(Protocol):
+    def describe(self, image: np.ndarray) -> np.ndarray: ...
+
+
+class CNNDescriptor:
+    """backend/descriptors.py:142-204 with a batched device path.
+
+    ``out_dim``: None keeps the reference's 2048-d ``flatten`` node.  BASELINE
+    config 2 asks for 512-d embeddings, which the reference's node does not have;
+    ``out_dim=512`` applies a fixed seeded 2048->512 Gaussian projection
+    (scaled 1/sqrt(2048)) after the network, on the device.
+    """
+
+    def __init__(self, model=DnnModels.RESNET, seed: int = 0, out_dim: int | None = None,
+                 device: str | None = None, dtype: torch.dtype = torch.float32):
+        self.model = model
+        self.seed = seed
+        self.out_dim = out_dim
+        self.device = torch.device(device or config.DEVICE)
+        self.dtype = dtype
+        self.preprocessor = None
+        self.feature_extractor = None
+        self.projection = None
+        self.initialize_model()
+
+    def initialize_model(self):
+        if self.model == DnnModels.RESNET:
+            self.preprocessor = self._preprocess_batch
+            net = resnet50_features(self.seed)
+            self.feature_extractor = net.to(self.device).to(memory_format=torch.channels_last)
+            if self.out_dim is not None and self.out_dim != 2048:
+                g = torch.Generator().manual_seed(self.seed + 1)
+                self.projection = (torch.randn(2048, self.out_dim, generator=g) / 2048 ** 0.5).to(self.device)
+        elif self.model == DnnModels.BiT:
+            raise NotImplementedError("google/bit-50 needs a network fetch (backend/descriptors.py:171-172)")
+        else:
+            raise ValueError(f"Model '{self.model}' not recognized for feature extraction")
+        self.feature_extractor.eval()
+        self._mean = torch.tensor(_MEAN, device=self.device).view(1, 3, 1, 1) * 255.0
+        self._std = torch.tensor(_STD, device=self.device).view(1, 3, 1, 1) * 255.0
+
+    # -- preprocessing: A.Resize(224,224, INTER_LINEAR) -> A.Normalize() -> ToTensorV2
+    def _preprocess_batch(self, images) -> torch.Tensor:
+        size = config.RESIZE_SIZE
+        out = []
+        for im in images:
+            t = torch.from_numpy(np.ascontiguousarray(im)).to(self.device, non_blocking=True)
+            if t.dim() != 3 or t.shape[2] != 3:
+                raise ValueError("expected an HWC 3-channel uint8 image")
+            t = t.permute(2, 0, 1).unsqueeze(0).float()
+            if t.shape[2] != size or t.shape[3] != size:
+                t = F.interpolate(t, size=(size, size), mode="bilinear", align_corners=False)
+            out.append(t)
+        x = torch.cat(out, 0)
+        x = (x - self._mean) / self._std  # (img - mean*255) / (std*255), channel order untouched
+        return x.contiguous(memory_format=torch.channels_last)
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.dtype != torch.float32:
+            with torch.autocast(self.device.type, dtype=self.dtype):
+                f = self.feature_extractor(x).float()
+        else:
+            f = self.feature_extractor(x)
+        if self.projection is not None:
+            f = f @ self.projection
+        return f
+
+    # -- batched entry points (new capability)
+    @torch.no_grad()
+    def extract_features_batch(self, images) -> torch.Tensor:
+        """list of HWC BGR uint8 arrays -> (B, d) float32 tensor ON THE DEVICE."""
+        return self._forward(self.preprocessor(images))
+
+    def describe_batch(self, images) -> torch.Tensor:
+        """(B, d) float32 CPU tensor."""
+        return self.extract_features_batch(images).cpu()
+
+    # -- the reference's entry points
+    def extract_features(self, image):
+        if self.model != DnnModels.RESNET:
+            raise Exception("Model not recognized")
+        return self._forward(self.preprocessor([image])).cpu().flatten()
+
+    def describe(self, image: np.ndarray):
+        with torch.no_grad():
+            return self.extract_features(image)
+
+    extract = describe  # name used by BASELINE.json's north_star
+
+
+class Describer:
+    """backend/descriptors.py:47-101.  Descriptors exposing ``describe_batch`` are fed
+    ``batch_size`` images per call; results and skip-on-error behaviour are unchanged."""
+
+    def __init__(self, descriptors: dict[str, SupportsDescribe], batch_size: int | None = None):
+        self.descriptors = self._validate_descriptors(descriptors)
+        self.batch_size = batch_size or config.DNN_BATCH_SIZE
+
+    def _validate_descriptors(self, descriptors):
+        if not descriptors:
+            raise Exception("No descriptors provided")
+        return descriptors
+
+    def read_image(self, path):
+        """BGR uint8 HxWx3 like cv2.imread(IMREAD_COLOR) (decoded with PIL here)."""
+        from PIL import Image
+
+        try:
+            with Image.open(str(path)) as im:
+                rgb = np.asarray(im.convert("RGB"))
+        except Exception:
+            raise Exception("Problem opening image")
+        return np.ascontiguousarray(rgb[:, :, ::-1]).astype(np.uint8)
+
+    def _flush(self, pending, descriptions):
+        if not pending:
+            return
+        paths, images = zip(*pending)
+        for d_name, descriptor in self.descriptors.items():
+            if hasattr(descriptor, "describe_batch"):
+                try:
+                    feats = descriptor.describe_batch(list(images))
+                    for f in feats:
+                        descriptions[d_name].append(f.reshape(1, -1))
+                    continue
+                except Exception as e:  # fall back to per-image so one bad image skips alone
+                    print(f"ERROR: batched describe failed ({e}); retrying per image")
+            for img_path, image in zip(paths, images):
+                try:
+                    description = descriptor.describe(image)
+                    if description is None:
+                        raise Exception(f"Couldn't describe image '{img_path}'.")
+                    if description.ndim == 1:
+                        description = description.reshape(1, -1)
+                    descriptions[d_name].append(description)
+                except Exception as e:
+                    print(f"ERROR: Problem describing image '{img_path}'\n '{e}'")
+        pending.clear()
+
+    def describe(self, images_paths, multiprocess=False) -> dict[str, list]:
+        descriptions: dict[str, list] = defaultdict(list)
+        pending = []
+        for img_path in np.asarray(images_paths).ravel().tolist():
+            try:
+                pending.append((img_path, self.read_image(img_path)))
+            except Exception as e:
+                print(f"ERROR: Problem describing image '{img_path}'\n '{e}'")
+                continue
+            if len(pending) >= self.batch_size:
+                self._flush(pending, descriptions)
+        self._flush(pending, descriptions)
+        return descriptions
+
+
+def describe_dataset(describer: Describer, images_paths: np.ndarray, prediction=False) -> list:
+    """backend/descriptors.py:104-139: chunk (n_jobs*2), thread-parallel describe, flatten
+    into a list of per-image (1, d) arrays.  Quirk 5.9-5 is kept: an existing
+    BOVW_CORNER_DESCRIPTIONS_PATH file short-circuits extraction even on the DNN path."""
+    import joblib
+    from joblib import Parallel, delayed
+
+    n_jobs = 1 if prediction else config.N_JOBS
+    if config.BOVW_CORNER_DESCRIPTIONS_PATH.exists() and not prediction:
+        print("Loading corner description features from local file.")
+        return joblib.load(str(config.BOVW_CORNER_DESCRIPTIONS_PATH))
+    paths_chunks = chunkIt(images_paths, n_jobs * 2)
+    print("Extracting features from {} images. Splitting in {} jobs.".format(images_paths.shape[0], len(paths_chunks)))
+    with Parallel(backend="threading", n_jobs=n_jobs) as parallel:
+        dicts = parallel(delayed(describer.describe)(paths, n_jobs > 1) for paths in paths_chunks)
+    descriptions = []
+    for descriptions_dict in dicts:
+        for key in descriptions_dict.keys():
+            for image_description in descriptions_dict[key]:
+                descriptions.append(image_description)
+    return descriptions

@@ -1,0 +1,96 @@
+"""Query side with the reference's names (backend/engine.py:46-65): ``run_image_query``
+over module-level ``index`` / ``images_paths`` / ``descriptor``, as the reference binds
+them (backend/engine.py:28-35,110-135).  ``load()`` does what the reference's
+``__main__`` block does for METHOD=DNN; the Flask route is a thin optional wrapper
+(serving plumbing is a "next" row)."""
+from __future__ import annotations
+
+import json
+import time
+
+import numpy as np
+import torch
+
+from . import faiss_compat as faiss
+from .config import Config, Method
+from .utils import get_image, get_images_paths
+
+config = Config()
+index = None
+images_paths = None
+descriptor = None
+
+
+def load(index_path=None, paths=None, desc=None):
+    """Bind the module globals (backend/engine.py:110-117 for METHOD=DNN)."""
+    global index, images_paths, descriptor
+    images_paths = get_images_paths() if paths is None else paths
+    index = faiss.read_index(str(index_path or config.DNN_INDEX_PATH))
+    print(f"There are {index.ntotal} images in the index.")
+    if desc is not None:
+        descriptor = desc
+    return index
+
+
+def run_image_query(image_features, n_images, normalize=False):
+    """backend/engine.py:46-65: tensor -> (1, d) float32, optional normalize_L2,
+    index.search, ravel, id -> path -> thumbnail."""
+    if isinstance(image_features, torch.Tensor):
+        image_features = image_features.detach().cpu().numpy().reshape(1, -1)
+    image_features = np.ascontiguousarray(image_features, dtype=np.float32)
+    if normalize:
+        faiss.normalize_L2(image_features)
+    distances, indices = index.search(image_features, n_images)
+    distances = distances.ravel().tolist()
+    indices = indices.ravel().tolist()
+    predictions = []
+    for dist, i in zip(distances, indices):
+        image_path = images_paths[i]
+        image = get_image(image_path)
+        predictions.append((dist, image, str(image_path)))
+    return predictions
+
+
+def run_image_queries(features, n_images, normalize=False):
+    """Batched form (new capability): (nq, d) features -> list of per-query predictions
+    with one index.search call."""
+    if isinstance(features, torch.Tensor):
+        features = features.detach().cpu().numpy()
+    features = np.ascontiguousarray(features, dtype=np.float32).reshape(len(features), -1)
+    if normalize:
+        faiss.normalize_L2(features)
+    D, I = index.search(features, n_images)
+    return [[(float(d), get_image(images_paths[i]), str(images_paths[i])) for d, i in zip(dr, ir)]
+            for dr, ir in zip(D.tolist(), I.tolist())]
+
+
+def create_app():
+    """POST /similar_images, multipart field ``image`` -> {"prediction": [[dist, b64, path], ...]}
+    (backend/engine.py:68-107; frontend/src/App.js:14-21)."""
+    import io
+
+    from flask import Flask, Response, request
+    from PIL import Image
+
+    app = Flask(__name__)
+
+    @app.after_request
+    def _cors(resp):  # flask_cors is not in this image; the reference enables CORS globally
+        resp.headers["Access-Control-Allow-Origin"] = "*"
+        return resp
+
+    @app.route("/similar_images", methods=["POST"])
+    def predict():
+        if not request.files:
+            return Response("No file uploaded", status=400)
+        rgb = np.asarray(Image.open(io.BytesIO(request.files["image"].read())).convert("RGB"))
+        image = np.ascontiguousarray(rgb[:, :, ::-1])  # BGR like cv2.imdecode (backend/engine.py:42)
+        start = time.time()
+        if config.METHOD != Method.DNN:
+            return Response("only METHOD=DNN is served", status=501)
+        image_features = descriptor.describe(image)
+        predictions = run_image_query(image_features, config.NUM_IMAGES_TO_RETURN)
+        print(f"Took {time.time() - start:.2f} seconds.")
+        return Response(response=json.dumps({"prediction": predictions}), status=200, mimetype="application/json")
+
+    return app

@@ -27,6 +27,28 @@ def get_images_paths():
     return paths
 
 
+def get_image(image_path):
+    """Thumbnail of an image as base64 JPEG (PNG if JPEG cannot encode it), None if the
+    file is missing (backend/utils.py:44-62).  Display only."""
+    import base64
+    import io
+
+    from PIL import Image
+
+    size = config.THUMBNAIL_SIZE, config.THUMBNAIL_SIZE
+    try:
+        img = Image.open(image_path, mode="r")
+    except FileNotFoundError:
+        return None
+    img.thumbnail(size, Image.LANCZOS)
+    buf = io.BytesIO()
+    try:
+        img.save(buf, format="JPEG")
+    except OSError:
+        img.save(buf, format="PNG")
+    return base64.encodebytes(buf.getvalue()).decode("ascii")
+
+
 def create_search_index(data_array, index_type="cosine"):
     """backend/utils.py:293-330.  'cosine' -> IndexFlatIP over rows normalised IN
     PLACE in the caller's array (quirk 5.9-6); 'l2' -> IndexFlatL2; then add.

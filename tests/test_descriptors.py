@@ -1,0 +1,106 @@
+"""CPU tests of the feature-extraction surface (backend/descriptors.py mirror)."""
+import numpy as np
+import pytest
+import torch
+
+from image_search_engine_amd import descriptors as D
+from image_search_engine_amd.config import Config, DnnModels
+from image_search_engine_amd.resnet import resnet50_features
+
+
+@pytest.fixture(scope="module")
+def cnn():
+    return D.CNNDescriptor(model=DnnModels.RESNET, device="cpu")
+
+
+def test_resnet50_layout_matches_published_architecture():
+    net = resnet50_features(0)
+    sd = net.state_dict()
+    # torchvision resnet50 key names (minus the fc head the reference cuts off at `flatten`)
+    for key in ("conv1.weight", "bn1.running_mean", "layer1.0.conv1.weight", "layer1.0.downsample.0.weight",
+                "layer2.3.bn3.weight", "layer3.5.conv2.weight", "layer4.2.conv3.weight", "layer4.0.downsample.1.bias"):
+        assert key in sd, key
+    assert not any(k.startswith("fc.") for k in sd)
+    assert sum(p.numel() for p in net.parameters()) == 23_508_032  # 25,557,032 - fc (2048*1000 + 1000)
+    assert sd["layer2.0.conv2.weight"].shape == (128, 128, 3, 3) and net.layer2[0].conv2.stride == (2, 2)  # v1.5
+    a, b = resnet50_features(0).state_dict(), resnet50_features(0).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)  # seeded init is reproducible
+
+
+def test_preprocess_is_resize_normalize_chw_without_channel_swap(cnn):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    x = cnn.preprocessor([img])
+    assert x.shape == (1, 3, 224, 224) and x.dtype == torch.float32
+    mean = np.array([0.485, 0.456, 0.406], np.float32)
+    std = np.array([0.229, 0.224, 0.225], np.float32)
+    ref = ((img.astype(np.float32) / 255.0 - mean) / std).transpose(2, 0, 1)  # A.Normalize + ToTensorV2
+    np.testing.assert_allclose(x[0].numpy(), ref, rtol=1e-5, atol=1e-5)
+    # bilinear resize uses half-pixel centres like cv2.INTER_LINEAR
+    big = np.zeros((448, 448, 3), np.uint8)
+    big[::2, ::2] = 200  # 2x2 box average -> 50 everywhere
+    y = cnn.preprocessor([big])
+    back = y[0].numpy() * std[:, None, None] * 255 + mean[:, None, None] * 255
+    np.testing.assert_allclose(back, 50.0, atol=1e-3)
+
+
+def test_describe_single_equals_batched_row(cnn):
+    rng = np.random.default_rng(1)
+    imgs = [rng.integers(0, 256, (224, 224, 3), dtype=np.uint8), rng.integers(0, 256, (100, 180, 3), dtype=np.uint8)]
+    f0 = cnn.describe(imgs[0])
+    assert isinstance(f0, torch.Tensor) and f0.shape == (2048,) and f0.dtype == torch.float32 and not f0.is_cuda
+    fb = cnn.describe_batch(imgs)
+    assert fb.shape == (2, 2048)
+    np.testing.assert_allclose(fb[0].numpy(), f0.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(fb[1].numpy(), cnn.describe(imgs[1]).numpy(), rtol=1e-4, atol=1e-4)
+    assert cnn.extract(imgs[0]).shape == (2048,)  # north_star alias
+
+
+def test_projection_to_512(cnn):
+    d512 = D.CNNDescriptor(device="cpu", out_dim=512)
+    img = np.random.default_rng(2).integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    f = d512.describe(img)
+    assert f.shape == (512,)
+    np.testing.assert_allclose(f.numpy(), (cnn.describe(img) @ d512.projection.cpu()).numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_describer_reads_bgr_skips_failures_and_keeps_order(tmp_path, cnn):
+    from PIL import Image
+
+    paths = []
+    for i in range(5):
+        arr = np.zeros((40, 50, 3), np.uint8)
+        arr[..., 0] = 10 * (i + 1)  # R
+        arr[..., 2] = 200            # B
+        p = tmp_path / f"im{i}.png"
+        Image.fromarray(arr).save(p)
+        paths.append(p)
+    paths.insert(2, tmp_path / "missing.png")
+    (tmp_path / "broken.png").write_bytes(b"not an image")
+    paths.append(tmp_path / "broken.png")
+    describer = D.Describer({"conv_features": cnn}, batch_size=2)
+    img = describer.read_image(paths[0])
+    assert img.dtype == np.uint8 and img.shape == (40, 50, 3)
+    assert img[0, 0, 0] == 200 and img[0, 0, 2] == 10  # BGR like cv2.imread
+    out = describer.describe(np.array(paths, dtype=object).reshape(-1, 1))
+    feats = out["conv_features"]
+    assert len(feats) == 5 and all(tuple(f.shape) == (1, 2048) for f in feats)  # 2 unreadable files skipped
+    np.testing.assert_allclose(np.asarray(feats[3]).ravel(), cnn.describe(describer.read_image(paths[4])).numpy(),
+                               rtol=1e-4, atol=1e-4)
+    with pytest.raises(Exception):
+        D.Describer({})
+
+
+def test_describe_dataset_flattens_chunks(tmp_path, cnn, monkeypatch):
+    from PIL import Image
+
+    paths = []
+    for i in range(3):
+        p = tmp_path / f"a{i}.jpg"
+        Image.fromarray(np.full((30, 30, 3), 40 * i, np.uint8)).save(p)
+        paths.append(p)
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "nope.joblib")
+    out = D.describe_dataset(D.Describer({"conv_features": cnn}), np.array(paths, dtype=object).reshape(-1, 1))
+    assert len(out) == 3 and all(tuple(o.shape) == (1, 2048) for o in out)
+    arr = np.concatenate([np.asarray(o) for o in out])  # backend/indexer.py:55
+    assert arr.shape == (3, 2048) and arr.dtype == np.float32
