@@ -102,51 +102,58 @@ struct ScanParams {
     const float* norms;  // [cap]
     const float* q;      // [nq][d]
     const u64* floor_keys;  // optional [nq]: only keys > floor enter (k > 64 passes)
-    u64* part;           // [nqt][nb][16][k]
+    u64* part;           // [nqt][nb][16 T][k]
     long long n;         // rows in the index
     int d, dp, qs_stride;
-    int nq, k, metric;
+    int nq, k, kb, metric;  // kb: block-list slots per query (16 or 32, >= k)
     uint32_t id_base;
     int tiles_total, tiles_per_block;
     int ablate;  // dev builds (-DISE_ABLATE): bit mask of phases to skip, from $ISE_ABLATE
-    unsigned long long* stamps;  // dev builds: [blocks][waves][8] s_memrealtime stamps (100 MHz), or null
+    unsigned long long* stamps;  // dev builds: [blocks][waves][16] stamps (0-7 s_memrealtime 100 MHz, 8-9 s_memtime), or null
 };
 #ifdef ISE_ABLATE
 #define ABL(bit) (p.ablate & (bit))
 #define STAMP(i)                                                                                   \
     do {                                                                                           \
         if (p.stamps && lane == 0)                                                                 \
-            p.stamps[((size_t)blockIdx.x * W + w) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();   \
+            p.stamps[((size_t)blockIdx.x * W + w) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();  \
+    } while (0)
+#define CSTAMP(i)                                                                                  \
+    do {                                                                                           \
+        if (p.stamps && lane == 0)                                                                 \
+            p.stamps[((size_t)blockIdx.x * W + w) * 16 + (i)] = __builtin_amdgcn_s_memtime();      \
     } while (0)
 #else
 #define ABL(bit) 0
 #define STAMP(i) do {} while (0)
+#define CSTAMP(i) do {} while (0)
 #endif
 
 #define TAU0 ((u64)0xFF7FFFFFu << 32) /* ord(FLT_MAX) << 32: strict gate score < FLT_MAX */
-#define KB 32                          /* boot-winner slots per query = largest k of one pass */
+#define CAP 16       /* slots of a wave's private candidate list; folded out at MERGE_TRIG */
+#define MERGE_TRIG 8
+#define KB_MAX 32    /* block-list slots per query (runtime kb = 16 or 32), >= k of one pass */
 
-// Wave-level selection: the min(k, #real) smallest of the keys held as
-// kk[e] = element (lane + 64 e), e < KPL (KEY_PAD = empty slot; elements with
-// 64 e >= n must be empty), written SORTED to dst[0..).  Returns the number
-// written; *kth = the k-th smallest key when k were written.
-// Quickselect on the key value with wave-uniform control flow (ballot counts),
-// then an all-pairs rank among the <= k winners only.  Real keys are unique and
-// lie strictly between 0 and KEY_PAD.
+// ---- wave-level selection primitives on 64-bit keys.  Keys are held as
+// kk[e] = element (lane + 64 e), e < KPL; KEY_PAD = empty slot; elements with
+// 64 e >= n must be empty.  Real keys are unique and lie strictly between 0 and
+// KEY_PAD.  Control flow is wave-uniform (ballot counts in SGPRs).
+
+// Exact: the min(k, #real) smallest keys, written SORTED to dst[0..).  Returns
+// the number written; *kth = the k-th smallest key when k were written.
+// Quickselect on the key value, then an all-pairs rank among the <= k winners.
 template <int KPL>
 __device__ __forceinline__ int wave_select(const u64 (&kk)[KPL], int n, int k, u64* dst, u64* kth) {
     int nreal = 0;
 #pragma unroll
     for (int e = 0; e < KPL; e++)
         if (64 * e < n) nreal += __popcll(__ballot(kk[e] != KEY_PAD));
-    u64 kstar = KEY_PAD - 1;  // fewer than k real keys: all of them win
-    if (nreal > k) {
+    u64 kstar = KEY_PAD - 1;  // all real keys are ranked; right when few keys are held
+    if (nreal > k && nreal > 40) {  // many keys: narrow to the k winners first (quickselect)
         u64 L = 0, H = KEY_PAD;  // the target lies in the open interval (L, H)
         int t = k - 1;           // its rank among the keys of that interval
         for (int round = 0;; round++) {
-            // pivot: an element of the interval, position rotated per round so that
-            // sorted input does not degrade the search
-            u64 P = 0;
+            u64 P = 0;  // pivot: an element of the interval, position rotated per round
             bool found = false;
             const int rot = (round * 23 + 7) & 63;
 #pragma unroll
@@ -155,8 +162,7 @@ __device__ __forceinline__ int wave_select(const u64 (&kk)[KPL], int n, int k, u
                     const u64 m = __ballot(kk[e] > L && kk[e] < H);
                     if (m) {
                         const u64 hi = (m >> rot) << rot;
-                        const int pick = __ffsll((long long)(hi ? hi : m)) - 1;
-                        P = readlane_u64(kk[e], pick);
+                        P = readlane_u64(kk[e], __ffsll((long long)(hi ? hi : m)) - 1);
                         found = true;
                     }
                 }
@@ -177,8 +183,7 @@ __device__ __forceinline__ int wave_select(const u64 (&kk)[KPL], int n, int k, u
             }
         }
     }
-    // rank among the winners (keys <= kstar); at most k of them
-    int rk[KPL];
+    int rk[KPL];  // rank among the winners (keys <= kstar); at most k of them
 #pragma unroll
     for (int e = 0; e < KPL; e++) rk[e] = 0;
 #pragma unroll
@@ -194,71 +199,157 @@ __device__ __forceinline__ int wave_select(const u64 (&kk)[KPL], int n, int k, u
             }
         }
     }
+    u64 kth_key = 0;
 #pragma unroll
-    for (int e = 0; e < KPL; e++)
-        if (64 * e < n && kk[e] <= kstar) dst[rk[e]] = kk[e];
+    for (int e = 0; e < KPL; e++) {
+        if (64 * e < n) {
+            const bool win = kk[e] <= kstar && rk[e] < k;
+            if (win) dst[rk[e]] = kk[e];
+            const u64 hit = __ballot(win && rk[e] == k - 1);
+            if (hit) kth_key = readlane_u64(kk[e], __ffsll((long long)hit) - 1);
+        }
+    }
     const int nw = min(nreal, k);
-    if (nw == k) *kth = kstar;
+    if (nw == k) *kth = kth_key;
     return nw;
 }
 
-// LDS bytes of one scan block (host mirror: scan_lds_bytes)
-#define CAP 16 /* slots of a wave's private candidate list; merged out at MERGE_TRIG */
-#define MERGE_TRIG 8
-__host__ __device__ constexpr size_t scan_lds_layout(int S, int waves) {
-    return (size_t)(QT * S + QT) * 4      /* qs, xn */
-           + (size_t)QT * 8               /* tauS */
-           + (size_t)QT * 4 * 2           /* bwc, lockS */
-           + (size_t)waves * QT * 4       /* cntS */
-           + (size_t)QT * KB * 8          /* bootw */
-           + (size_t)waves * QT * CAP * 8 /* cand (boot staging aliases it: 16 x W*16 keys) */;
+// Windowed cut: finds a key P with kmin <= #(keys <= P) <= kmax and writes those
+// keys UNSORTED to dst (all real keys if there are at most kmax).  Returns the
+// count; *cut = P when the count reached kmin.  A valid, cheap threshold: the
+// kmin-th smallest key is <= P.  Window width makes this take a few rounds only.
+template <int KPL>
+__device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, int kmax, u64* dst, u64* cut) {
+    const int lane = threadIdx.x & 63;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    int nreal = 0;
+    u64 mx = 0;
+#pragma unroll
+    for (int e = 0; e < KPL; e++)
+        if (64 * e < n) nreal += __popcll(__ballot(kk[e] != KEY_PAD));
+    u64 P = KEY_PAD - 1;
+    int cnt = nreal;
+    if (nreal > kmax) {
+        u64 L = 0, H = KEY_PAD;
+        int base = 0;  // #(keys <= L)
+        for (int round = 0;; round++) {
+            u64 piv = 0;
+            bool found = false;
+            const int rot = (round * 23 + 7) & 63;
+#pragma unroll
+            for (int e = 0; e < KPL; e++) {
+                if (64 * e < n && !found) {
+                    const u64 m = __ballot(kk[e] > L && kk[e] < H);
+                    if (m) {
+                        const u64 hi = (m >> rot) << rot;
+                        piv = readlane_u64(kk[e], __ffsll((long long)(hi ? hi : m)) - 1);
+                        found = true;
+                    }
+                }
+            }
+            int c = base;
+#pragma unroll
+            for (int e = 0; e < KPL; e++)
+                if (64 * e < n) c += __popcll(__ballot(kk[e] > L && kk[e] <= piv));
+            if (c < kmin) {
+                L = piv;
+                base = c;
+            } else if (c > kmax) {
+                H = piv;
+            } else {
+                P = piv;
+                cnt = c;
+                break;
+            }
+        }
+    } else if (nreal >= kmin) {
+        // every real key stays: the cut is the largest of them
+#pragma unroll
+        for (int e = 0; e < KPL; e++)
+            if (64 * e < n) {
+                const u64 v = kk[e] == KEY_PAD ? 0ull : kk[e];
+                mx = mx > v ? mx : v;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 other = __shfl_xor(mx, o);
+            mx = mx > other ? mx : other;
+        }
+        P = mx;
+    }
+    int off = 0;
+#pragma unroll
+    for (int e = 0; e < KPL; e++) {
+        if (64 * e < n) {
+            const bool keep = kk[e] <= P;  // P < KEY_PAD: empty slots never kept
+            const u64 m = __ballot(keep);
+            if (keep) dst[off + __popcll(m & lt_mask)] = kk[e];
+            off += __popcll(m);
+        }
+    }
+    if (cnt >= kmin) *cut = P;
+    return cnt;
+}
+
+// LDS bytes of one scan block (host and device agree through this function)
+__host__ __device__ constexpr size_t scan_lds_layout(int S, int waves, int T, int kb) {
+    return (size_t)(16 * T) * ((size_t)S * 4 + 4 /* qs, xn */ + 8 /* tauS */ + 8 /* bwc, lockS */ +
+                               (size_t)waves * 4 /* cntS */ + (size_t)kb * 8 /* bootw */ +
+                               (size_t)waves * CAP * 8 /* cand; boot staging aliases it */);
 }
 
 // CH : k-steps (16 floats each) per register chunk; dp/16 is a multiple of CH
 // W  : waves per block
+// T  : query tiles of 16 per pass: the index stream is read once for 16*T queries
+//      (one MFMA column block and two accumulator chains per tile)
 //
-// Top-k bookkeeping (all off the streaming path):
-//   boot   every wave scores its first tile and dumps all 16x16 keys; two block
-//          barriers later each query has the sorted k best of those W*16 rows
-//          (bootw) and a block-wide threshold tauS[q] = their k-th key.
-//   steady a lane holds 4 scores per tile for one query and compares them with
-//          its copy of the threshold; survivors (a few per wave over the whole
-//          kernel) are appended to the wave's private list; at MERGE_TRIG entries
-//          the wave takes the query's LDS lock, folds its list into bootw and
-//          publishes the new k-th key, so tauS tracks the block's running k-th best.
-//   final  per query, one wave selects the top-k of bootw + what is left in the W
-//          private lists and writes the block's sorted list.
-template <int CH, int W>
-__global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p) {
+// Top-k bookkeeping (all off the streaming path, per query):
+//   boot   every wave scores its first row tile and dumps all 16x16 keys; two block
+//          barriers later the query has a block list bootw of between k and kb of
+//          the best of those W*16 rows (windowed cut) and a threshold tauS = the cut.
+//   steady a lane holds 4 scores per row tile for one query per query tile and
+//          compares them with its copy of the threshold; survivors (a few per wave
+//          over the whole kernel) are appended to the wave's private list; at
+//          MERGE_TRIG entries the wave takes the query's LDS lock, folds its list
+//          into bootw (exact top-k of the union, sorted) and publishes the new k-th
+//          key, so tauS tracks the block's running k-th best.
+//   final  one wave selects the exact sorted top-k of bootw + what is left in the W
+//          private lists and writes the block's list to HBM.
+template <int CH, int W, int T>
+__global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) void scan_kernel(const ScanParams p) {
     constexpr int BLOCK_THREADS = W * 64;
-    constexpr int TPR = BLOCK_THREADS / QT;       // threads staging one query row
-    constexpr int KPLB = (W * 16 + 63) / 64;      // boot: keys per lane
-    constexpr int KPLF = (KB + W * CAP + 63) / 64;  // final: keys per lane (worst case)
-    static_assert(KB + CAP <= 64 && MERGE_TRIG + 4 <= CAP && W * 16 * 16 <= W * QT * CAP, "list sizes");
+    constexpr int NQ = 16 * T;                        // queries per block pass
+    constexpr int TPR = BLOCK_THREADS / 16;           // threads staging one query row (per tile)
+    constexpr int KPLB = (W * 16 + 63) / 64;          // boot: keys per lane
+    constexpr int KPLF = (KB_MAX + W * CAP + 63) / 64;  // final: keys per lane (worst case)
+    static_assert(KB_MAX + CAP <= 64 && MERGE_TRIG + 4 <= CAP, "list sizes");
     extern __shared__ __align__(16) unsigned char smem[];
     const int S = p.qs_stride;
-    float* qs = reinterpret_cast<float*>(smem);                 // [16][S]
-    float* xn = qs + QT * S;                                    // [16]
-    u64* tauS = reinterpret_cast<u64*>(xn + QT);                // [16]
-    int* bwc = reinterpret_cast<int*>(tauS + QT);               // [16]
-    int* lockS = bwc + QT;                                      // [16]
-    int* cntS = lockS + QT;                                     // [W][16]
-    u64* bootw = reinterpret_cast<u64*>(cntS + W * QT);         // [16][KB]
-    u64* cand = bootw + QT * KB;                                // [W][16][CAP]
-    u64* boot = cand;                                           // [16][W*16], dead before cand is used
+    const int kb = p.kb;
+    float* qs = reinterpret_cast<float*>(smem);                 // [NQ][S]
+    float* xn = qs + NQ * S;                                    // [NQ]
+    u64* tauS = reinterpret_cast<u64*>(xn + NQ);                // [NQ]
+    int* bwc = reinterpret_cast<int*>(tauS + NQ);               // [NQ]
+    int* lockS = bwc + NQ;                                      // [NQ]
+    int* cntS = lockS + NQ;                                     // [W][NQ]
+    u64* bootw = reinterpret_cast<u64*>(cntS + W * NQ);         // [NQ][kb]
+    u64* cand = bootw + NQ * kb;                                // [W][NQ][CAP]
+    u64* boot = cand;                                           // [NQ][W*16], dead before cand is used
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.y * QT;
-    const int nqt = min(QT, p.nq - q0);
+    const int q0 = blockIdx.y * NQ;
+    const int nqt = min(NQ, p.nq - q0);  // valid queries of this pass
     const int k = p.k;
     const int nsteps = p.dp >> 4;
     const int t0 = blockIdx.x * p.tiles_per_block;
     const int t1 = min(t0 + p.tiles_per_block, p.tiles_total);
     const bool l2 = p.metric == ISE_METRIC_L2;
+    STAMP(0);
 
     auto load_chunk = [&](f32x4(&a)[CH], int tile, int s0) {
         const float* base = p.xb + ((size_t)tile * 16 + c) * p.dp + 4 * g + 16 * s0;
+        if (ABL(32)) base = p.xb + (size_t)c * p.dp + 4 * g;  // dev: every chunk re-reads one L1-hot line set
 #pragma unroll
         for (int s = 0; s < CH; s++) a[s] = *reinterpret_cast<const f32x4*>(base + 16 * s);
     };
@@ -266,22 +357,32 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
         return *reinterpret_cast<const f32x4*>(p.norms + (size_t)tile * 16 + 4 * g);
     };
 
-    STAMP(0);
-    // ---- the first index chunk is requested before anything else: its HBM
-    // latency overlaps the query staging below
-    int tile = t0 + w;
-    const bool has_work = tile < t1 && !ABL(16);
-    f32x4 a0[CH], a1[CH];
-    f32x4 yn_cur = {0.f, 0.f, 0.f, 0.f};
+    // ---- register ring of R index chunks (CH k-steps x 16 rows each).  Chunk positions
+    // run tile-major over this wave's row tiles (t0 + w, + W, ...).  The first R - 1
+    // chunks are requested before anything else: their HBM latency overlaps the query
+    // staging below.
+    constexpr int R = T == 1 ? 2 : (T == 2 ? 4 : 3);
+    const bool has_work = (t0 + w) < t1 && !ABL(16);
+    f32x4 A[R][CH];
+    int ltile = t0 + w, ls0 = 0;  // position of the next chunk to LOAD (clamped at the end)
+    auto advance_load = [&]() {
+        int ns = ls0 + CH, nt = ltile;
+        if (ns >= nsteps) { ns = 0; nt = ltile + W; }
+        if (nt < t1) { ltile = nt; ls0 = ns; }  // past the end: keep re-reading the last chunk
+    };
     if (has_work) {
-        load_chunk(a0, tile, 0);
-        yn_cur = load_norms(tile);
+#pragma unroll
+        for (int j = 0; j < R - 1; j++) {
+            load_chunk(A[j], ltile, ls0);
+            advance_load();
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- stage the query tile (zero padded to 16 x S) and |x|^2: TPR threads per row
-    {
-        const int cc = tid / TPR, t = tid % TPR;
+    // ---- stage the query tiles (zero padded to NQ x S) and |x|^2: TPR threads per row
+#pragma unroll
+    for (int tq = 0; tq < T; tq++) {
+        const int cc = tq * 16 + tid / TPR, t = tid % TPR;
         const bool rowok = cc < nqt && !ABL(1);
         const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
         float sn = 0.f;
@@ -306,190 +407,248 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
 #pragma unroll
         for (int o = TPR / 2; o > 0; o >>= 1) sn += __shfl_xor(sn, o);
         if (t == 0) xn[cc] = sn;
-        if (tid < QT) {
-            tauS[tid] = TAU0;
-            bwc[tid] = 0;
-            lockS[tid] = 0;
-        }
+    }
+    for (int i = tid; i < NQ; i += BLOCK_THREADS) {
+        tauS[i] = TAU0;
+        bwc[i] = 0;
+        lockS[i] = 0;
     }
     __syncthreads();
     STAMP(1);
+    CSTAMP(8);
 
-    const float xq_n = xn[c];
     const float* qrow = qs + c * S + 4 * g;
-    const u64 qmask = 0x0001000100010001ull << c;
-    const u64 lt_mask = (1ull << lane) - 1ull;
-    const u64 key_floor = (p.floor_keys && c < nqt) ? p.floor_keys[q0 + c] : 0ull;
     const bool use_floor = p.floor_keys != nullptr;
 
-    u64 tau = TAU0;
-    int cnt = 0;
+    float xq_n[T];
+    u64 tau[T];
+    int cnt[T];
+    f32x4 acc0[T], acc1[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        xq_n[t] = xn[t * 16 + c];
+        tau[t] = TAU0;
+        cnt[t] = 0;
+        acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     bool booted = false;
-    u64* mybuf = cand + (size_t)(w * QT + c) * CAP;
 
-    // fold the wave's private list of query qq into the block's sorted list bootw[qq]
-    // (top-k of their union) under the query's LDS lock; publish the new k-th key
-    auto merge_out = [&](int qq) {
-        const int n_ = __builtin_amdgcn_readlane(cnt, qq);
-        const u64* buf = cand + (size_t)(w * QT + qq) * CAP;
+    // fold the wave's private list of query qq = 16 t + cq into the block list bootw[qq]
+    // (exact sorted top-k of their union) under the query's LDS lock; publish the k-th key
+    auto merge_out = [&](int t, int cq) {
+        const int qq = t * 16 + cq;
+        const int n_ = __builtin_amdgcn_readlane(cnt[t], cq);
+        const u64* buf = cand + (size_t)(w * NQ + qq) * CAP;
         if (lane == 0)
             while (atomicCAS(&lockS[qq], 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
         wave_lds_fence();
         const int nb = bwc[qq];
         u64 kk[1];
-        kk[0] = lane < nb ? bootw[qq * KB + lane] : (lane - nb < n_ ? buf[lane - nb] : KEY_PAD);
+        kk[0] = lane < nb ? bootw[qq * kb + lane] : (lane - nb < n_ ? buf[lane - nb] : KEY_PAD);
         wave_lds_fence();
         u64 ktau = KEY_PAD;
-        const int nw = wave_select<1>(kk, nb + n_, k, bootw + qq * KB, &ktau);  // nb + n_ <= KB + CAP <= 64
+        const int nw = wave_select<1>(kk, nb + n_, k, bootw + qq * kb, &ktau);  // nb + n_ <= kb + CAP <= 64
         if (lane == 0) {
             bwc[qq] = nw;
-            if (nw == k) tauS[qq] = ktau;  // <= the old value: the union only adds keys
+            if (nw == k) tauS[qq] = ktau;  // never above the old value: the union only adds keys
         }
         wave_lds_fence();
         if (lane == 0) atomicExch(&lockS[qq], 0);
-        if (c == qq) {
-            cnt = 0;
-            if (nw == k) tau = min_u64(tau, ktau);
+        if (c == cq) {
+            cnt[t] = 0;
+            if (nw == k) tau[t] = min_u64(tau[t], ktau);
         }
     };
 
-    // boot: all W*16 first-tile keys of a query -> its k best + the block threshold
-    auto boot_phase = [&](const u64(&key)[4]) {
+    // boot: all W*16 first-tile keys of a query -> block list + block threshold
+    auto boot_phase = [&](const u64(&key)[T][4]) {
         STAMP(2);
 #pragma unroll
-        for (int j = 0; j < 4; j++) boot[(size_t)c * (W * 16) + w * 16 + 4 * g + j] = key[j];
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) boot[(size_t)(t * 16 + c) * (W * 16) + w * 16 + 4 * g + j] = key[t][j];
         __syncthreads();
-        for (int qq = w; qq < QT; qq += W) {
+        STAMP(7);
+        for (int qq = w; qq < NQ; qq += W) {
             u64 kk[KPLB];
 #pragma unroll
             for (int e = 0; e < KPLB; e++)
                 kk[e] = (lane + 64 * e) < W * 16 ? boot[(size_t)qq * (W * 16) + lane + 64 * e] : KEY_PAD;
             u64 ktau = TAU0;
-            const int nw = wave_select<KPLB>(kk, W * 16, k, bootw + qq * KB, &ktau);
+            const int nw = wave_cut<KPLB>(kk, W * 16, k, kb, bootw + qq * kb, &ktau);
             if (lane == 0) {
                 bwc[qq] = nw;
-                tauS[qq] = ktau;
+                tauS[qq] = ktau;  // TAU0 when fewer than k real keys were seen
             }
         }
         __syncthreads();
-        tau = tauS[c];
+#pragma unroll
+        for (int t = 0; t < T; t++) tau[t] = tauS[t * 16 + c];
         booted = true;
         STAMP(3);
     };
 
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-
-    auto epilogue = [&](int etile, f32x4 yn) {
-        const f32x4 dot = acc0 + acc1;
-        acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // score of (query tile t, row slot j) exactly as it is keyed: squared L2 in the
+    // |x|^2 + |y|^2 - 2 x.y form clamped at 0 (NaN kept), or minus the inner product
+    auto score = [&](int t, float dotj, float ynj) -> float {
+        if (l2) {
+            const float sc = (xq_n[t] + ynj) - 2.f * dotj;
+            return sc < 0.f ? 0.f : sc;  // keeps NaN (Faiss: if (dis < 0) dis = 0)
+        }
+        return -dotj;
+    };
+    auto make_keys = [&](int etile, const f32x4(&sc)[T], u64(&key)[T][4]) {
         const long long row0 = (long long)etile * 16 + 4 * g;
-        u64 key[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float sc;
-            if (l2) {
-                sc = (xq_n + yn[j]) - 2.f * dot[j];
-                sc = sc < 0.f ? 0.f : sc;  // keeps NaN (Faiss: if (dis < 0) dis = 0)
-            } else {
-                sc = -dot[j];
-            }
-            bool ok = (row0 + j < p.n) && (sc < FLT_MAX) && (c < nqt);
-            const u64 kj = ((u64)ord_f32(sc) << 32) | (uint32_t)((uint32_t)(row0 + j) + p.id_base);
-            if (use_floor) ok = ok && (kj > key_floor);
-            key[j] = ok ? kj : KEY_PAD;
-        }
-        if (!booted) {
-            boot_phase(key);
-            return;
-        }
-        tau = min_u64(tau, tauS[c]);
-        const bool pend = key[0] < tau || key[1] < tau || key[2] < tau || key[3] < tau;
-        if (__any(pend) && !ABL(2)) {
+        for (int t = 0; t < T; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool v = key[j] < tau;
-                const u64 m = __ballot(v);
-                if (m) {
-                    const u64 mq = m & qmask;
-                    if (v) mybuf[cnt + __popcll(mq & lt_mask)] = key[j];
-                    cnt += __popcll(mq);
-                    u64 nm = __ballot(cnt >= MERGE_TRIG) & 0xFFFFull;
-                    while (nm) {
-                        const int qq = __ffsll((long long)nm) - 1;
-                        nm &= nm - 1;
-                        merge_out(qq);
+                bool ok = (row0 + j < p.n) && (sc[t][j] < FLT_MAX) && (t * 16 + c < nqt);
+                const u64 kj = ((u64)ord_f32(sc[t][j]) << 32) | (uint32_t)((uint32_t)(row0 + j) + p.id_base);
+                if (use_floor) ok = ok && (kj > p.floor_keys[q0 + min(t * 16 + c, nqt - 1)]);  // multi-pass k only
+                key[t][j] = ok ? kj : KEY_PAD;
+            }
+    };
+
+    float tau_sc[T];  // float image of tau's score part: a conservative pre-filter
+#pragma unroll
+    for (int t = 0; t < T; t++) tau_sc[t] = FLT_MAX;
+
+    auto epilogue = [&](int etile, f32x4 yn) {
+        f32x4 sc[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const f32x4 dot = acc0[t] + acc1[t];
+            acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++) sc[t][j] = score(t, dot[j], yn[j]);
+        }
+        if (!booted) {
+            u64 key[T][4];
+            make_keys(etile, sc, key);
+            boot_phase(key);
+#pragma unroll
+            for (int t = 0; t < T; t++) tau_sc[t] = unord_f32((uint32_t)(tau[t] >> 32));
+            return;
+        }
+        // fast path: a row can only enter if its score does not exceed the threshold's
+        // score (ties on the score are settled by the exact key compare below)
+        bool pend = false;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            tau[t] = min_u64(tau[t], tauS[t * 16 + c]);  // other waves' merges tighten it
+            tau_sc[t] = unord_f32((uint32_t)(tau[t] >> 32));
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++)
+            pend = pend || sc[t][0] <= tau_sc[t] || sc[t][1] <= tau_sc[t] || sc[t][2] <= tau_sc[t] ||
+                   sc[t][3] <= tau_sc[t];
+        if (__any(pend) && !ABL(2)) {
+            u64 key[T][4];
+            make_keys(etile, sc, key);
+            const u64 qmask = 0x0001000100010001ull << c;  // lanes holding the same query
+            const u64 lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                u64* mybuf = cand + (size_t)(w * NQ + t * 16 + c) * CAP;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool v = key[t][j] < tau[t];
+                    const u64 m = __ballot(v);
+                    if (m) {
+                        const u64 mq = m & qmask;
+                        if (v) mybuf[cnt[t] + __popcll(mq & lt_mask)] = key[t][j];
+                        cnt[t] += __popcll(mq);
+                        u64 nm = __ballot(cnt[t] >= MERGE_TRIG) & 0xFFFFull;
+                        while (nm) {
+                            const int cq = __ffsll((long long)nm) - 1;
+                            nm &= nm - 1;
+                            merge_out(t, cq);
+                        }
                     }
+                }
+                tau_sc[t] = unord_f32((uint32_t)(tau[t] >> 32));
+            }
+        }
+    };
+
+    // B operand (queries, from LDS) is software-pipelined one k-step ahead of the MFMAs
+    // that consume it, across chunk boundaries too: bcur holds the B fragments of the
+    // next step to be computed.
+    f32x4 bcur[T];
+    auto load_b = [&](f32x4(&b)[T], int step) {
+#pragma unroll
+        for (int t = 0; t < T; t++) b[t] = *reinterpret_cast<const f32x4*>(qrow + (size_t)t * 16 * S + 16 * step);
+    };
+    auto compute_chunk = [&](const f32x4(&a)[CH], int s0, int next_first_step) {
+#pragma unroll
+        for (int s = 0; s < CH; s++) {
+            f32x4 bnext[T];
+            load_b(bnext, s + 1 < CH ? s0 + s + 1 : next_first_step);
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], bcur[t][0], acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], bcur[t][1], acc1[t], 0, 0, 0);
+                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], bcur[t][2], acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], bcur[t][3], acc1[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < T; t++) bcur[t] = bnext[t];
+        }
+    };
+
+    // ---- main loop.  Each step: request the chunk R - 1 positions ahead (unconditionally:
+    // no control-flow join between a load and its use, so hipcc emits counted vmcnt waits
+    // and the ring stays in flight), then run the MFMAs of the oldest chunk.  The row
+    // norms of the tile being computed are requested first, so the epilogue's wait on them
+    // never drains the younger index loads.
+    if (has_work) {
+        int tile = t0 + w, s0 = 0;  // position of the chunk being COMPUTED
+        load_b(bcur, 0);
+        bool done = false;
+        while (!done) {
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                if (!done) {
+                    const f32x4 yn = load_norms(tile);
+                    load_chunk(A[(j + R - 1) % R], ltile, ls0);
+                    advance_load();
+                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs
+                    int ns0 = s0 + CH, ntile = tile;
+                    if (ns0 >= nsteps) { ns0 = 0; ntile = tile + W; }
+                    compute_chunk(A[j], s0, ns0);
+                    if (ns0 == 0 && !ABL(8)) epilogue(tile, yn);
+                    done = ntile >= t1;
+                    tile = ntile; s0 = ns0;
                 }
             }
         }
-    };
-
-    auto compute_chunk = [&](const f32x4(&a)[CH], int s0) {
-#pragma unroll
-        for (int s = 0; s < CH; s++) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(qrow + 16 * (s0 + s));
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], b[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], b[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], b[3], acc1, 0, 0, 0);
-        }
-    };
-
-    // ---- main loop: two register chunks in flight, tiles interleaved by wave.
-    // Loads are issued unconditionally (the last iteration re-reads its own
-    // chunk) so that no control-flow join sits between a load and its use:
-    // hipcc then emits counted vmcnt waits and the prefetch stays in flight.
-    if (has_work) {
-        int s0 = 0;
-        for (;;) {
-            int ns0 = s0 + CH, ntile = tile;
-            if (ns0 >= nsteps) { ns0 = 0; ntile = tile + W; }
-            bool has_next = ntile < t1;
-            {
-                const int lt = has_next ? ntile : tile, ls = has_next ? ns0 : s0;
-                load_chunk(a1, lt, ls);
-                const f32x4 yn_nx = load_norms(lt);
-                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs
-                compute_chunk(a0, s0);
-                if (s0 + CH >= nsteps && !ABL(8)) epilogue(tile, yn_cur);
-                yn_cur = yn_nx;
-            }
-            if (!has_next) break;
-            tile = ntile; s0 = ns0;
-
-            ns0 = s0 + CH; ntile = tile;
-            if (ns0 >= nsteps) { ns0 = 0; ntile = tile + W; }
-            has_next = ntile < t1;
-            {
-                const int lt = has_next ? ntile : tile, ls = has_next ? ns0 : s0;
-                load_chunk(a0, lt, ls);
-                const f32x4 yn_nx = load_norms(lt);
-                __builtin_amdgcn_sched_barrier(0);
-                compute_chunk(a1, s0);
-                if (s0 + CH >= nsteps && !ABL(8)) epilogue(tile, yn_cur);
-                yn_cur = yn_nx;
-            }
-            if (!has_next) break;
-            tile = ntile; s0 = ns0;
-        }
     }
-    if (!booted) {  // a wave without a tile still takes part in the two boot barriers
-        const u64 none[4] = {KEY_PAD, KEY_PAD, KEY_PAD, KEY_PAD};
+    if (!booted) {  // a wave without a row tile still takes part in the two boot barriers
+        u64 none[T][4];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) none[t][j] = KEY_PAD;
         boot_phase(none);
     }
 
-    // ---- final: per query, rank bootw + the W private lists, write the sorted top-k
+    // ---- final: per query, exact sorted top-k of bootw + the W private lists
     STAMP(4);
-    if (g == 0) cntS[w * QT + c] = cnt;
+    CSTAMP(9);
+#pragma unroll
+    for (int t = 0; t < T; t++)
+        if (g == 0) cntS[w * NQ + t * 16 + c] = cnt[t];
     __syncthreads();
     STAMP(5);
-    for (int qq = w; qq < QT && !ABL(4); qq += W) {
+    for (int qq = w; qq < NQ && !ABL(4); qq += W) {
         int P[W + 2];
         P[0] = 0;
         P[1] = bwc[qq];
 #pragma unroll
-        for (int i = 0; i < W; i++) P[i + 2] = P[i + 1] + cntS[i * QT + qq];
+        for (int i = 0; i < W; i++) P[i + 2] = P[i + 1] + cntS[i * NQ + qq];
         const int n = P[W + 1];
         u64 kk[KPLF];
 #pragma unroll
@@ -497,17 +656,17 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
             kk[e] = KEY_PAD;
             const int idx = lane + 64 * e;
             if (64 * e < n) {
-                if (idx < P[1]) kk[e] = bootw[qq * KB + idx];
+                if (idx < P[1]) kk[e] = bootw[qq * kb + idx];
 #pragma unroll
                 for (int i = 0; i < W; i++)
                     if (idx >= P[i + 1] && idx < P[i + 2])
-                        kk[e] = cand[(size_t)(i * QT + qq) * CAP + idx - P[i + 1]];
+                        kk[e] = cand[(size_t)(i * NQ + qq) * CAP + idx - P[i + 1]];
             }
         }
-        u64* out = p.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * QT + qq) * k;
+        u64* out = p.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NQ + qq) * k;
         u64 kth_unused;
         const int nw = wave_select<KPLF>(kk, n, k, out, &kth_unused);
-        if (lane >= nw && lane < k) out[lane] = KEY_PAD;  // k <= KB <= 64
+        if (lane >= nw && lane < k) out[lane] = KEY_PAD;  // k <= KB_MAX <= 64
     }
     STAMP(6);
 }
@@ -520,7 +679,8 @@ __global__ __launch_bounds__(W * 64, W / 2) void scan_kernel(const ScanParams p)
 struct MergeParams {
     const u64* lists;
     long long stride_list;   // elements between consecutive lists
-    long long stride_qtile;  // elements between consecutive 16-query tiles
+    long long stride_qtile;  // elements between consecutive query tiles
+    int qt;                  // queries per tile
     int n_lists, nq, k, metric;
     float* D;        // [nq][k] or null
     long long* I;    // [nq][k] or null
@@ -542,7 +702,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
     __shared__ u64 wmin[2][MERGE_THREADS / 64];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int k = p.k;
-    const u64* base = p.lists + (size_t)(q >> 4) * p.stride_qtile + (size_t)(q & 15) * k;
+    const u64* base = p.lists + (size_t)(q / p.qt) * p.stride_qtile + (size_t)(q % p.qt) * k;
     const u64* lst[MERGE_LPT];
     int pos[MERGE_LPT];
     u64 cur[MERGE_LPT];
@@ -662,11 +822,20 @@ struct ise_index {
     long long n = 0, cap = 0;
     float* xb = nullptr;
     float* norms = nullptr;
-    // workspace (grown lazily, guarded by mu)
-    u64* part = nullptr;
-    size_t part_elems = 0;
-    u64* keys_tmp = nullptr;  // [nq][k] scratch for multi-pass k
-    size_t keys_tmp_elems = 0;
+    // workspaces (grown lazily, guarded by mu): calls rotate through NWS slots and a
+    // slot's reuse is ordered behind its previous use with an event, so searches on
+    // different streams may be in flight together
+    struct WorkSlot {
+        u64* part = nullptr;
+        size_t part_elems = 0;
+        u64* keys_tmp = nullptr;  // multi-pass k scratch
+        size_t keys_tmp_elems = 0;
+        hipEvent_t done = nullptr;
+        bool used = false;
+    };
+    static constexpr int NWS = 4;
+    WorkSlot ws[NWS];
+    unsigned ws_next = 0;
     // host-API staging
     hipStream_t stream = nullptr;
     float* q_dev = nullptr;  size_t q_elems = 0;
@@ -689,7 +858,9 @@ static int qs_stride_for(int dp) {
     return dp + pad;
 }
 #define KPASS_MAX 32 /* largest k one scan pass selects; larger k runs floor-keyed passes */
-static size_t scan_lds_bytes(int dp, int waves) { return scan_lds_layout(qs_stride_for(dp), waves); }
+static size_t scan_lds_bytes(int dp, int waves, int T, int kb) {
+    return scan_lds_layout(qs_stride_for(dp), waves, T, kb);
+}
 
 extern "C" int ise_version(void) { return 100; }
 extern "C" const char* ise_last_error(void) { return g_err.c_str(); }
@@ -749,18 +920,21 @@ extern "C" int ise_index_create(ise_index_t** out, int d, int metric, int device
 static void free_all(ise_index* h) {
     if (h->xb) (void)hipFree(h->xb);
     if (h->norms) (void)hipFree(h->norms);
-    if (h->part) (void)hipFree(h->part);
-    if (h->keys_tmp) (void)hipFree(h->keys_tmp);
+    for (auto& w : h->ws) {
+        if (w.part) (void)hipFree(w.part);
+        if (w.keys_tmp) (void)hipFree(w.keys_tmp);
+        if (w.done) (void)hipEventDestroy(w.done);
+        w = ise_index::WorkSlot();
+    }
     if (h->q_dev) (void)hipFree(h->q_dev);
     if (h->D_dev) (void)hipFree(h->D_dev);
     if (h->I_dev) (void)hipFree(h->I_dev);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     h->xb = h->norms = nullptr;
-    h->part = h->keys_tmp = nullptr;
     h->q_dev = h->D_dev = nullptr;
     h->I_dev = nullptr;
     h->h_stage = nullptr;
-    h->part_elems = h->keys_tmp_elems = h->q_elems = h->out_elems = h->h_stage_bytes = 0;
+    h->q_elems = h->out_elems = h->h_stage_bytes = 0;
     h->n = h->cap = 0;
 }
 
@@ -919,54 +1093,89 @@ extern "C" int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n,
 
 // ---- search
 #define LDS_LIMIT (160 * 1024)
-template <int CH, int W>
+template <int CH, int W, int T>
 static void launch_one(dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     static bool attr_done = false;  // benign race: the attribute is idempotent
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CH, W>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CH, W, T>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr_done = true;
     }
-    hipLaunchKernelGGL((scan_kernel<CH, W>), grid, dim3(W * 64), lds, st, sp);
+    hipLaunchKernelGGL((scan_kernel<CH, W, T>), grid, dim3(W * 64), lds, st, sp);
 }
-template <int W>
+template <int W, int T>
 static void launch_scan_ch(int ch, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     switch (ch) {
-        case 8: launch_one<8, W>(grid, lds, st, sp); break;
-        case 4: launch_one<4, W>(grid, lds, st, sp); break;
-        case 2: launch_one<2, W>(grid, lds, st, sp); break;
-        default: launch_one<1, W>(grid, lds, st, sp); break;
+        case 8: launch_one<8, W, T>(grid, lds, st, sp); break;
+        case 4: launch_one<4, W, T>(grid, lds, st, sp); break;
+        case 2: launch_one<2, W, T>(grid, lds, st, sp); break;
+        default: launch_one<1, W, T>(grid, lds, st, sp); break;
     }
 }
-static void launch_scan(int ch, int waves, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
-    if (waves == 8) launch_scan_ch<8>(ch, grid, lds, st, sp);
-    else launch_scan_ch<4>(ch, grid, lds, st, sp);
+template <int W>
+static void launch_scan_w(int ch, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
+    if (T == 1) launch_scan_ch<W, 1>(ch, grid, lds, st, sp);
+    else if (T == 2) launch_scan_ch<W, 2>(ch, grid, lds, st, sp);
+    else launch_scan_ch<W, 3>(ch, grid, lds, st, sp);
+}
+static void launch_scan(int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
+    if (waves == 8) launch_scan_w<8>(ch, T, grid, lds, st, sp);
+    else launch_scan_w<4>(ch, T, grid, lds, st, sp);
 }
 
 struct ScanPlan {
-    int nblocks, tiles_total, tiles_per_block, nqt, ch, kpass, waves;
+    int nblocks, tiles_total, tiles_per_block, nqt, ch, kpass, kb, waves, T;
     size_t lds;
 };
 
+// pick (query tiles per pass T, waves per block) for nq queries: the largest T <= 3
+// that the batch can use and whose LDS image fits, preferring 8 waves
 static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     pl->kpass = k < KPASS_MAX ? k : KPASS_MAX;
+    pl->kb = pl->kpass <= 16 ? 16 : 32;
     pl->ch = chunk_steps(h->dp);
-    pl->waves = 8;
-    pl->lds = scan_lds_bytes(h->dp, 8);
-    if (pl->lds > LDS_LIMIT) {
-        pl->waves = 4;
-        pl->lds = scan_lds_bytes(h->dp, 4);
-    }
-    if (pl->lds > LDS_LIMIT)
-        return fail(ISE_E_INVALID, "d too large: the 16-query tile must fit the 160 KiB LDS (d <= 2048)");
-    pl->tiles_total = (int)((h->n + 15) / 16);
-    int blocks_per_cu = pl->lds <= LDS_LIMIT / 2 ? 2 : 1;
 #ifdef ISE_ABLATE
-    if (const char* e = getenv("ISE_PLAN")) {  // dev: "waves,blocks_per_cu"
-        int wv = 8, bpc = 2;
-        if (sscanf(e, "%d,%d", &wv, &bpc) == 2 && (wv == 4 || wv == 8) && bpc >= 1) {
+    if (const char* e = getenv("ISE_CH")) {  // dev: force a smaller chunk (must divide dp/16)
+        const int ch = atoi(e);
+        if ((ch == 1 || ch == 2 || ch == 4 || ch == 8) && (h->dp / 16) % ch == 0) pl->ch = ch;
+    }
+#endif
+    // relative time of one pass over the index with T query tiles (measured, 1M x 512)
+    static const double pass_cost[4] = {0.0, 1.0, 1.08, 1.25};
+    int tmax = 3;
+#ifdef ISE_ABLATE
+    if (const char* e = getenv("ISE_TMAX")) tmax = std::min(3, std::max(1, atoi(e)));
+#endif
+    pl->T = 0;
+    double best = 0;
+    for (int t = 1; t <= tmax; t++) {
+        int wv = 0;
+        size_t lds = 0;
+        for (int cand_w = 8; cand_w >= 4 && !wv; cand_w -= 4) {
+            lds = scan_lds_bytes(h->dp, cand_w, t, pl->kb);
+            if (lds <= LDS_LIMIT) wv = cand_w;
+        }
+        if (!wv) break;
+        const double cost = (double)((nq + 16 * t - 1) / (16 * t)) * pass_cost[t];
+        if (!pl->T || cost < best - 1e-9) {
+            pl->T = t;
             pl->waves = wv;
-            pl->lds = scan_lds_bytes(h->dp, wv);
+            pl->lds = lds;
+            best = cost;
+        }
+    }
+    if (!pl->T) return fail(ISE_E_INVALID, "d too large: a 16-query tile must fit the 160 KiB LDS (d <= ~2400)");
+    // one query tile runs 16 waves per CU at <= 128 VGPRs: 4-step chunks (2 x 4 KB in flight per
+    // wave) measured faster than 8-step ones there (no spills, more waves' worth of loads)
+    if (pl->T == 1 && pl->ch > 4) pl->ch = 4;
+    pl->tiles_total = (int)((h->n + 15) / 16);
+    int blocks_per_cu = (pl->T == 1 && pl->lds <= LDS_LIMIT / 2) ? 2 : 1;
+#ifdef ISE_ABLATE
+    if (const char* e = getenv("ISE_PLAN")) {  // dev: "waves,blocks_per_cu" (T = 1 only)
+        int wv = 8, bpc = 2;
+        if (pl->T == 1 && sscanf(e, "%d,%d", &wv, &bpc) == 2 && (wv == 4 || wv == 8) && bpc >= 1) {
+            pl->waves = wv;
+            pl->lds = scan_lds_bytes(h->dp, wv, 1, pl->kb);
             blocks_per_cu = bpc;
         }
     }
@@ -980,29 +1189,30 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     if (pl->tiles_per_block < 1) pl->tiles_per_block = 1;
     pl->nblocks = (pl->tiles_total + pl->tiles_per_block - 1) / pl->tiles_per_block;
     if (pl->nblocks < 1) pl->nblocks = 1;
-    pl->nqt = (int)((nq + QT - 1) / QT);
+    pl->nqt = (int)((nq + 16 * pl->T - 1) / (16 * pl->T));
     return ISE_OK;
 }
 
 // workspace: part [nqt][nb][16][kpass]; for k > kpass additionally
 // keys_tmp = keys_all [nq][k] | floor [nq] | pass_keys [nq][kpass]
-static int ensure_workspace(ise_index* h, const ScanPlan& pl, long long nq, int k) {
-    const size_t need = (size_t)pl.nqt * pl.nblocks * QT * pl.kpass;
-    if (need > h->part_elems) {
-        if (h->part) (void)hipFree(h->part);
-        h->part = nullptr;
-        h->part_elems = 0;
-        HIP_TRY(hipMalloc(&h->part, need * sizeof(u64)));
-        h->part_elems = need;
+static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long long nq, int k) {
+    if (!w->done) HIP_TRY(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
+    const size_t need = (size_t)pl.nqt * pl.nblocks * (16 * pl.T) * pl.kpass;
+    if (need > w->part_elems) {
+        if (w->part) (void)hipFree(w->part);  // hipFree waits for outstanding work
+        w->part = nullptr;
+        w->part_elems = 0;
+        HIP_TRY(hipMalloc(&w->part, need * sizeof(u64)));
+        w->part_elems = need;
     }
     if (k > pl.kpass) {
         const size_t need2 = (size_t)nq * ((size_t)k + 1 + pl.kpass);
-        if (need2 > h->keys_tmp_elems) {
-            if (h->keys_tmp) (void)hipFree(h->keys_tmp);
-            h->keys_tmp = nullptr;
-            h->keys_tmp_elems = 0;
-            HIP_TRY(hipMalloc(&h->keys_tmp, need2 * sizeof(u64)));
-            h->keys_tmp_elems = need2;
+        if (need2 > w->keys_tmp_elems) {
+            if (w->keys_tmp) (void)hipFree(w->keys_tmp);
+            w->keys_tmp = nullptr;
+            w->keys_tmp_elems = 0;
+            HIP_TRY(hipMalloc(&w->keys_tmp, need2 * sizeof(u64)));
+            w->keys_tmp_elems = need2;
         }
     }
     return ISE_OK;
@@ -1044,13 +1254,22 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     ScanPlan pl;
     int rc = make_plan(h, nq, k, &pl);
     if (rc) return rc;
-    rc = ensure_workspace(h, pl, nq, k);
+    ise_index::WorkSlot* w = &h->ws[h->ws_next++ % ise_index::NWS];
+    rc = ensure_workspace(w, pl, nq, k);
     if (rc) return rc;
+    if (w->used) HIP_TRY(hipStreamWaitEvent(st, w->done, 0));
+    struct Release {  // whatever path returns, later users of the slot wait for this call
+        ise_index::WorkSlot* w;
+        hipStream_t st;
+        ~Release() {
+            if (hipEventRecord(w->done, st) == hipSuccess) w->used = true;
+        }
+    } release{w, st};
 
     ScanParams sp;
-    sp.xb = h->xb; sp.norms = h->norms; sp.q = q_dev; sp.floor_keys = nullptr; sp.part = h->part;
+    sp.xb = h->xb; sp.norms = h->norms; sp.q = q_dev; sp.floor_keys = nullptr; sp.part = w->part;
     sp.n = h->n; sp.d = h->d; sp.dp = h->dp; sp.qs_stride = qs_stride_for(h->dp);
-    sp.nq = (int)nq; sp.k = pl.kpass; sp.metric = h->metric; sp.id_base = id_base;
+    sp.nq = (int)nq; sp.k = pl.kpass; sp.kb = pl.kb; sp.metric = h->metric; sp.id_base = id_base;
     sp.tiles_total = pl.tiles_total; sp.tiles_per_block = pl.tiles_per_block;
     sp.ablate = 0;
     sp.stamps = nullptr;
@@ -1060,15 +1279,16 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
 #endif
 
     MergeParams mp;
-    mp.lists = h->part; mp.stride_list = (long long)QT * pl.kpass;
-    mp.stride_qtile = (long long)pl.nblocks * QT * pl.kpass;
+    const int NQ = 16 * pl.T;
+    mp.lists = w->part; mp.stride_list = (long long)NQ * pl.kpass;
+    mp.stride_qtile = (long long)pl.nblocks * NQ * pl.kpass; mp.qt = NQ;
     mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.k = pl.kpass; mp.metric = h->metric;
 
     const dim3 grid((unsigned)pl.nblocks, (unsigned)pl.nqt);
     if (k <= pl.kpass) {
         mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out;
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
-        launch_scan(pl.ch, pl.waves, grid, pl.lds, st, sp);
+        launch_scan(pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
@@ -1078,13 +1298,13 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     }
     // k > KPASS_MAX: passes of KPASS_MAX; a pass only admits keys above the
     // previous pass's last key (keys are totally ordered and unique)
-    u64* keys_all = keys_out ? keys_out : h->keys_tmp;      // [nq][k]
-    u64* floor_dev = h->keys_tmp + (size_t)nq * k;          // [nq]
+    u64* keys_all = keys_out ? keys_out : w->keys_tmp;      // [nq][k]
+    u64* floor_dev = w->keys_tmp + (size_t)nq * k;          // [nq]
     u64* pass_keys = floor_dev + nq;                        // [nq][kpass]
     for (int off = 0; off < k; off += pl.kpass) {
         sp.floor_keys = off ? floor_dev : nullptr;
         mp.D = nullptr; mp.I = nullptr; mp.keys_out = pass_keys;
-        launch_scan(pl.ch, pl.waves, grid, pl.lds, st, sp);
+        launch_scan(pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
         HIP_TRY(hipGetLastError());
@@ -1223,7 +1443,7 @@ extern "C" int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int6
     MergeParams mp;
     mp.lists = (const u64*)keys_dev;
     mp.stride_list = (long long)nq * k;
-    mp.stride_qtile = (long long)QT * k;
+    mp.stride_qtile = (long long)k; mp.qt = 1;
     mp.n_lists = n_lists; mp.nq = (int)nq; mp.k = k; mp.metric = metric;
     mp.D = D_dev; mp.I = (long long*)I_dev; mp.keys_out = nullptr;
     hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, (hipStream_t)stream, mp);

@@ -23,8 +23,10 @@
  *   - ids are row numbers in insertion order (+ id_base); a (sharded) index
  *     holds fewer than 2^32 rows.
  *   - concurrent *_host calls on one handle are safe (serialised per handle);
- *     *_device calls on one handle must be issued from one thread at a time
- *     and onto one stream at a time (they share the handle's workspace).
+ *     *_device calls on one handle may target different streams (the handle
+ *     rotates through a few workspaces and orders their reuse with events, so
+ *     independent batches on different streams overlap on the GPU); results of
+ *     a call are ordered after it on its own stream only.
  */
 #ifndef ISE_KNN_H
 #define ISE_KNN_H
