@@ -131,7 +131,7 @@ struct ScanParams {
 
 #define TAU0 ((u64)0xFF7FFFFFu << 32) /* ord(FLT_MAX) << 32: strict gate score < FLT_MAX */
 #define CAP 16       /* slots of a wave's private candidate list; folded out at MERGE_TRIG */
-#define MERGE_TRIG 8
+#define MERGE_TRIG 12
 #define KB_MAX 32    /* block-list slots per query (runtime kb = 16 or 32), >= k of one pass */
 
 // ---- wave-level selection primitives on 64-bit keys.  Keys are held as
@@ -357,10 +357,32 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
         return *reinterpret_cast<const f32x4*>(p.norms + (size_t)tile * 16 + 4 * g);
     };
 
+    // ---- query staging, step 1: REQUEST the query tiles first (small, L2-resident after
+    // the first block): issued behind the index prefetch they would queue for microseconds.
+    // TPR threads per query row, QV 16-byte pieces per thread and tile.
+    const bool vec_q = (p.d & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.q) & 15) == 0) && S <= 4 * TPR * 8;
+    constexpr int QV = 8;  // up to 8 float4 per thread per tile: S <= 32 * TPR floats
+    f32x4 qv[T][QV];
+    if (vec_q) {
+        const int d4 = p.d >> 2;
+#pragma unroll
+        for (int tq = 0; tq < T; tq++) {
+            const int cc = tq * 16 + tid / TPR, t = tid % TPR;
+            const bool rowok = cc < nqt && !ABL(1);
+            const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
+#pragma unroll
+            for (int i = 0; i < QV; i++) {
+                const int j4 = t + i * TPR;
+                qv[tq][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rowok && j4 < d4) qv[tq][i] = *reinterpret_cast<const f32x4*>(src + 4 * j4);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- register ring of R index chunks (CH k-steps x 16 rows each).  Chunk positions
     // run tile-major over this wave's row tiles (t0 + w, + W, ...).  The first R - 1
-    // chunks are requested before anything else: their HBM latency overlaps the query
-    // staging below.
+    // chunks are requested now: their HBM latency overlaps the rest of the staging.
     constexpr int R = T == 1 ? 2 : (T == 2 ? 4 : 3);
     const bool has_work = (t0 + w) < t1 && !ABL(16);
     f32x4 A[R][CH];
@@ -379,25 +401,28 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- stage the query tiles (zero padded to NQ x S) and |x|^2: TPR threads per row
+    // ---- query staging, step 2: into LDS (zero padded to NQ x S) with |x|^2
 #pragma unroll
     for (int tq = 0; tq < T; tq++) {
         const int cc = tq * 16 + tid / TPR, t = tid % TPR;
-        const bool rowok = cc < nqt && !ABL(1);
-        const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
         float sn = 0.f;
-        if ((p.d & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.q) & 15) == 0)) {
-            const int d4 = p.d >> 2, S4 = S >> 2;
-            for (int j4 = t; j4 < S4; j4 += TPR) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (rowok && j4 < d4) v = *reinterpret_cast<const f32x4*>(src + 4 * j4);
-                *reinterpret_cast<f32x4*>(qs + cc * S + 4 * j4) = v;
-                sn = fmaf(v[0], v[0], sn);
-                sn = fmaf(v[1], v[1], sn);
-                sn = fmaf(v[2], v[2], sn);
-                sn = fmaf(v[3], v[3], sn);
+        if (vec_q) {
+            const int S4 = S >> 2;
+#pragma unroll
+            for (int i = 0; i < QV; i++) {
+                const int j4 = t + i * TPR;
+                if (j4 < S4) {
+                    const f32x4 v = qv[tq][i];
+                    *reinterpret_cast<f32x4*>(qs + cc * S + 4 * j4) = v;
+                    sn = fmaf(v[0], v[0], sn);
+                    sn = fmaf(v[1], v[1], sn);
+                    sn = fmaf(v[2], v[2], sn);
+                    sn = fmaf(v[3], v[3], sn);
+                }
             }
-        } else {
+        } else {  // odd d, unaligned queries or very long rows: scalar path
+            const bool rowok = cc < nqt && !ABL(1);
+            const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
             for (int j = t; j < S; j += TPR) {
                 const float v = (rowok && j < p.d) ? src[j] : 0.f;
                 qs[cc * S + j] = v;
