@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("ISE_KNN_LIB") or os.path.join(_HERE, "csrc", "libise_
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
 MAX_K = 2048
+STORE_F32, STORE_BF16 = 0, 1
 
 E_INVALID, E_HIP, E_NOMEM, E_NODEVICE = -1, -2, -3, -4
 
@@ -37,6 +38,7 @@ PROTOTYPES = [
     ("ise_device_count", _int, [ctypes.POINTER(_int)]),
     ("ise_device_arch", _int, [_int, ctypes.c_char_p, _int]),
     ("ise_index_create", _int, [ctypes.POINTER(_vp), _int, _int, _int]),
+    ("ise_index_create_ex", _int, [ctypes.POINTER(_vp), _int, _int, _int, _int]),
     ("ise_index_destroy", _int, [_vp]),
     ("ise_index_reset", _int, [_vp]),
     ("ise_index_info", _int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), _i64p, ctypes.POINTER(_int)]),

@@ -43,6 +43,8 @@
 #include "../../include/ise_knn.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 #define KEY_PAD (~0ull)
@@ -98,13 +100,14 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // ---------------------------------------------------------------- scan kernel
 struct ScanParams {
-    const float* xb;     // [cap][dp]
+    const void* xb;      // [cap][dp] float32 or bf16 rows; 16-byte "slots": row_slots per row
     const float* norms;  // [cap]
     const float* q;      // [nq][d]
     const u64* floor_keys;  // optional [nq]: only keys > floor enter (k > 64 passes)
     u64* part;           // [nqt][nb][16 T][k]
     long long n;         // rows in the index
-    int d, dp, qs_stride;
+    int d, dp, qs_stride;  // qs_stride: LDS query row stride in floats (f32) / bf16 pairs... see SS
+    int row_slots;         // 16-byte slots per index row = dp * elem_size / 16; one k-step = 4 slots
     int nq, k, kb, metric;  // kb: block-list slots per query (16 or 32, >= k)
     uint32_t id_base;
     int tiles_total, tiles_per_block;
@@ -315,7 +318,7 @@ __host__ __device__ constexpr size_t scan_lds_layout(int S, int waves, int T, in
 //          key, so tauS tracks the block's running k-th best.
 //   final  one wave selects the exact sorted top-k of bootw + what is left in the W
 //          private lists and writes the block's list to HBM.
-template <int CH, int W, int T>
+template <int CH, int W, int T, bool BF16>
 __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) void scan_kernel(const ScanParams p) {
     constexpr int BLOCK_THREADS = W * 64;
     constexpr int NQ = 16 * T;                        // queries per block pass
@@ -341,17 +344,18 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     const int q0 = blockIdx.y * NQ;
     const int nqt = min(NQ, p.nq - q0);  // valid queries of this pass
     const int k = p.k;
-    const int nsteps = p.dp >> 4;
+    const int nsteps = p.row_slots >> 2;  // one k-step = 64 bytes of a row: 16 floats or 32 bf16
     const int t0 = blockIdx.x * p.tiles_per_block;
     const int t1 = min(t0 + p.tiles_per_block, p.tiles_total);
     const bool l2 = p.metric == ISE_METRIC_L2;
     STAMP(0);
 
     auto load_chunk = [&](f32x4(&a)[CH], int tile, int s0) {
-        const float* base = p.xb + ((size_t)tile * 16 + c) * p.dp + 4 * g + 16 * s0;
-        if (ABL(32)) base = p.xb + (size_t)c * p.dp + 4 * g;  // dev: every chunk re-reads one L1-hot line set
+        const char* base = static_cast<const char*>(p.xb) +
+                           ((((size_t)tile * 16 + c) * p.row_slots + 4 * s0 + g) << 4);
+        if (ABL(32)) base = static_cast<const char*>(p.xb) + (((size_t)c * p.row_slots + g) << 4);  // dev: L1-hot
 #pragma unroll
-        for (int s = 0; s < CH; s++) a[s] = *reinterpret_cast<const f32x4*>(base + 16 * s);
+        for (int s = 0; s < CH; s++) a[s] = *reinterpret_cast<const f32x4*>(base + 64 * s);
     };
     auto load_norms = [&](int tile) -> f32x4 {
         return *reinterpret_cast<const f32x4*>(p.norms + (size_t)tile * 16 + 4 * g);
@@ -360,21 +364,31 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     // ---- query staging, step 1: REQUEST the query tiles first (small, L2-resident after
     // the first block): issued behind the index prefetch they would queue for microseconds.
     // TPR threads per query row, QV 16-byte pieces per thread and tile.
-    const bool vec_q = (p.d & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.q) & 15) == 0) && S <= 4 * TPR * 8;
-    constexpr int QV = 8;  // up to 8 float4 per thread per tile: S <= 32 * TPR floats
+    // A thread handles 16-byte LDS slots j4 = t, t + TPR, ...: 4 floats (f32 store) or 8
+    // bf16 converted from 8 floats (bf16 store), i.e. FPS float4 loads per slot.
+    constexpr int FPS = BF16 ? 2 : 1;
+    constexpr int QV = 8;              // float4 registers per thread and tile
+    constexpr int QVS = QV / FPS;      // slots per thread and tile
+    const int S4 = S >> 2;             // 16-byte slots per LDS query row
+    const int dslots = BF16 ? (p.d >> 3) : (p.d >> 2);  // slots that carry data (vector path only)
+    const bool vec_q = (p.d & (BF16 ? 7 : 3)) == 0 && ((reinterpret_cast<uintptr_t>(p.q) & 15) == 0) &&
+                       S4 <= TPR * QVS;
     f32x4 qv[T][QV];
     if (vec_q) {
-        const int d4 = p.d >> 2;
 #pragma unroll
         for (int tq = 0; tq < T; tq++) {
             const int cc = tq * 16 + tid / TPR, t = tid % TPR;
             const bool rowok = cc < nqt && !ABL(1);
             const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
 #pragma unroll
-            for (int i = 0; i < QV; i++) {
+            for (int i = 0; i < QVS; i++) {
                 const int j4 = t + i * TPR;
-                qv[tq][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rowok && j4 < d4) qv[tq][i] = *reinterpret_cast<const f32x4*>(src + 4 * j4);
+#pragma unroll
+                for (int f = 0; f < FPS; f++) {
+                    qv[tq][i * FPS + f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (rowok && j4 < dslots)
+                        qv[tq][i * FPS + f] = *reinterpret_cast<const f32x4*>(src + 4 * (j4 * FPS + f));
+                }
             }
         }
     }
@@ -401,32 +415,62 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- query staging, step 2: into LDS (zero padded to NQ x S) with |x|^2
+    // ---- query staging, step 2: into LDS (zero padded to NQ x S units) with |x|^2.  With bf16
+    // storage the queries are rounded to bf16 as well and |x|^2 is taken of the rounded values.
+    auto to_bf16_pair = [](float lo, float hi) -> uint32_t {
+        const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+        return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+    };
+    auto bf16_round = [](float v) -> float { return (float)(__bf16)v; };
 #pragma unroll
     for (int tq = 0; tq < T; tq++) {
         const int cc = tq * 16 + tid / TPR, t = tid % TPR;
         float sn = 0.f;
         if (vec_q) {
-            const int S4 = S >> 2;
 #pragma unroll
-            for (int i = 0; i < QV; i++) {
+            for (int i = 0; i < QVS; i++) {
                 const int j4 = t + i * TPR;
                 if (j4 < S4) {
-                    const f32x4 v = qv[tq][i];
-                    *reinterpret_cast<f32x4*>(qs + cc * S + 4 * j4) = v;
-                    sn = fmaf(v[0], v[0], sn);
-                    sn = fmaf(v[1], v[1], sn);
-                    sn = fmaf(v[2], v[2], sn);
-                    sn = fmaf(v[3], v[3], sn);
+                    if (BF16) {
+                        const f32x4 v0 = qv[tq][i * FPS], v1 = qv[tq][i * FPS + FPS - 1];
+                        u32x4 o;
+                        o[0] = to_bf16_pair(v0[0], v0[1]);
+                        o[1] = to_bf16_pair(v0[2], v0[3]);
+                        o[2] = to_bf16_pair(v1[0], v1[1]);
+                        o[3] = to_bf16_pair(v1[2], v1[3]);
+                        *reinterpret_cast<u32x4*>(qs + cc * S + 4 * j4) = o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float r0 = bf16_round(v0[e]), r1 = bf16_round(v1[e]);
+                            sn = fmaf(r0, r0, sn);
+                            sn = fmaf(r1, r1, sn);
+                        }
+                    } else {
+                        const f32x4 v = qv[tq][i];
+                        *reinterpret_cast<f32x4*>(qs + cc * S + 4 * j4) = v;
+                        sn = fmaf(v[0], v[0], sn);
+                        sn = fmaf(v[1], v[1], sn);
+                        sn = fmaf(v[2], v[2], sn);
+                        sn = fmaf(v[3], v[3], sn);
+                    }
                 }
             }
-        } else {  // odd d, unaligned queries or very long rows: scalar path
+        } else {  // odd d, unaligned queries or very long rows: scalar path, one 4-byte unit at a time
             const bool rowok = cc < nqt && !ABL(1);
             const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
             for (int j = t; j < S; j += TPR) {
-                const float v = (rowok && j < p.d) ? src[j] : 0.f;
-                qs[cc * S + j] = v;
-                sn = fmaf(v, v, sn);
+                if (BF16) {
+                    const float lo = (rowok && 2 * j < p.d) ? src[2 * j] : 0.f;
+                    const float hi = (rowok && 2 * j + 1 < p.d) ? src[2 * j + 1] : 0.f;
+                    reinterpret_cast<uint32_t*>(qs)[cc * S + j] = to_bf16_pair(lo, hi);
+                    const float r0 = bf16_round(lo), r1 = bf16_round(hi);
+                    sn = fmaf(r0, r0, sn);
+                    sn = fmaf(r1, r1, sn);
+                } else {
+                    const float v = (rowok && j < p.d) ? src[j] : 0.f;
+                    qs[cc * S + j] = v;
+                    sn = fmaf(v, v, sn);
+                }
             }
         }
 #pragma unroll
@@ -614,10 +658,16 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
             load_b(bnext, s + 1 < CH ? s0 + s + 1 : next_first_step);
 #pragma unroll
             for (int t = 0; t < T; t++) {
-                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], bcur[t][0], acc0[t], 0, 0, 0);
-                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], bcur[t][1], acc1[t], 0, 0, 0);
-                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], bcur[t][2], acc0[t], 0, 0, 0);
-                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], bcur[t][3], acc1[t], 0, 0, 0);
+                if (BF16) {  // one 16x16x32 bf16 MFMA per k-step (8 bf16 per lane and operand)
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, a[s]), bv = __builtin_bit_cast(bf16x8, bcur[t]);
+                    if (s & 1) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc1[t], 0, 0, 0);
+                    else acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc0[t], 0, 0, 0);
+                } else {     // four 16x16x4 fp32 MFMAs per k-step (exact fp32 fmaf chains)
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], bcur[t][0], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], bcur[t][1], acc1[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], bcur[t][2], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], bcur[t][3], acc1[t], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int t = 0; t < T; t++) bcur[t] = bnext[t];
@@ -784,6 +834,50 @@ __global__ __launch_bounds__(256) void norms_kernel(const float* __restrict__ x,
     if (lane == 0) out[r] = s;
 }
 
+// |y|^2 of bf16 rows (the values the bf16 scan multiplies), fp32 accumulation
+__global__ __launch_bounds__(256) void norms_bf16_kernel(const __bf16* __restrict__ x, long long row0, long long n,
+                                                         int dp, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = row0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= row0 + n) return;
+    const __bf16* xr = x + (size_t)r * dp;
+    float s = 0.f;
+    for (int j = lane * 8; j < dp; j += 512) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + j);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float f = (float)v[e];
+            s = fmaf(f, f, s);
+        }
+    }
+    s = wave_sum_f32(s);
+    if (lane == 0) out[r] = s;
+}
+
+// float32 rows (unpadded) -> padded bf16 index rows (round to nearest even)
+__global__ __launch_bounds__(256) void pad_rows_bf16_kernel(const float* __restrict__ src, long long n, int d,
+                                                            __bf16* __restrict__ dst, int dp) {
+    const long long total = n * dp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / dp;
+        const int j = (int)(i - r * dp);
+        dst[i] = (__bf16)(j < d ? src[(size_t)r * d + j] : 0.f);
+    }
+}
+
+// padded bf16 rows -> float32 rows of d (reconstruct / write_index)
+__global__ __launch_bounds__(256) void unpack_rows_bf16_kernel(const __bf16* __restrict__ src, long long n, int d,
+                                                               int dp, float* __restrict__ dst) {
+    const long long total = n * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / d;
+        const int j = (int)(i - r * d);
+        dst[i] = (float)src[(size_t)r * dp + j];
+    }
+}
+
 // copy n rows of d floats (unpadded, src) into the padded index layout
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, long long n, int d,
                                                        float* __restrict__ dst, int dp) {
@@ -844,8 +938,9 @@ struct DeviceGuard {
 
 struct ise_index {
     int d = 0, dp = 0, metric = ISE_METRIC_L2, device = 0;
+    int storage = ISE_STORE_F32;  // element type of xb
     long long n = 0, cap = 0;
-    float* xb = nullptr;
+    void* xb = nullptr;
     float* norms = nullptr;
     // workspaces (grown lazily, guarded by mu): calls rotate through NWS slots and a
     // slot's reuse is ordered behind its previous use with an event, so searches on
@@ -870,21 +965,31 @@ struct ise_index {
     std::mutex mu;
 };
 
-static int pad_dim(int d) { return d > 64 ? (d + 63) / 64 * 64 : (d + 15) / 16 * 16; }
-static int chunk_steps(int dp) {
-    const int steps = dp / 16;
+// rows are padded to whole k-steps of 64 bytes (16 floats / 32 bf16); rows longer than
+// 4 steps to a multiple of 4 steps so that wider register chunks divide them
+static int elem_size(int storage) { return storage == ISE_STORE_BF16 ? 2 : 4; }
+static int pad_dim(int d, int storage) {
+    const int per_step = 64 / elem_size(storage);
+    const int steps = (d + per_step - 1) / per_step;
+    return (steps > 4 ? (steps + 3) / 4 * 4 : steps) * per_step;
+}
+static size_t row_bytes(const ise_index* h) { return (size_t)h->dp * elem_size(h->storage); }
+static int chunk_steps(const ise_index* h) {
+    const int steps = (int)(row_bytes(h) / 64);
     for (int ch = 8; ch > 1; ch >>= 1)
         if (steps % ch == 0) return ch;
     return 1;
 }
-static int qs_stride_for(int dp) {
-    // (stride/4) % 16 == 2 makes the 16x4 ds_read_b128 pattern conflict-free
-    const int pad = ((2 - (dp / 4)) % 16 + 16) % 16 * 4;
-    return dp + pad;
+// LDS query row stride in 4-byte units: (stride/4) % 16 == 2 makes the 16 rows x 4 k-groups
+// ds_read_b128 pattern bank-conflict-free
+static int qs_stride_for(const ise_index* h) {
+    const int units = (int)(row_bytes(h) / 4);
+    const int pad = ((2 - (units / 4)) % 16 + 16) % 16 * 4;
+    return units + pad;
 }
 #define KPASS_MAX 32 /* largest k one scan pass selects; larger k runs floor-keyed passes */
-static size_t scan_lds_bytes(int dp, int waves, int T, int kb) {
-    return scan_lds_layout(qs_stride_for(dp), waves, T, kb);
+static size_t scan_lds_bytes(const ise_index* h, int waves, int T, int kb) {
+    return scan_lds_layout(qs_stride_for(h), waves, T, kb);
 }
 
 extern "C" int ise_version(void) { return 100; }
@@ -911,9 +1016,15 @@ extern "C" int ise_device_arch(int device, char* buf, int buflen) {
 }
 
 extern "C" int ise_index_create(ise_index_t** out, int d, int metric, int device) {
+    return ise_index_create_ex(out, d, metric, device, ISE_STORE_F32);
+}
+
+extern "C" int ise_index_create_ex(ise_index_t** out, int d, int metric, int device, int storage) {
     if (!out) return fail(ISE_E_INVALID, "out is NULL");
     *out = nullptr;
     if (d <= 0) return fail(ISE_E_INVALID, "d must be positive");
+    if (storage != ISE_STORE_F32 && storage != ISE_STORE_BF16)
+        return fail(ISE_E_INVALID, "storage must be ISE_STORE_F32 or ISE_STORE_BF16");
     if (metric != ISE_METRIC_L2 && metric != ISE_METRIC_INNER_PRODUCT)
         return fail(ISE_E_INVALID, "metric must be ISE_METRIC_L2 or ISE_METRIC_INNER_PRODUCT");
     int ndev = 0;
@@ -928,7 +1039,8 @@ extern "C" int ise_index_create(ise_index_t** out, int d, int metric, int device
     ise_index* h = new (std::nothrow) ise_index();
     if (!h) return fail(ISE_E_NOMEM, "host allocation failed");
     h->d = d;
-    h->dp = pad_dim(d);
+    h->storage = storage;
+    h->dp = pad_dim(d, storage);
     h->metric = metric;
     h->device = device;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1004,19 +1116,20 @@ static int reserve_rows(ise_index* h, long long need, hipStream_t st) {
     long long want = need;
     if (cap > 0 && want < cap + cap / 2) want = cap + cap / 2;  // geometric growth on re-add
     want = (want + 15) / 16 * 16;
-    float* nx = nullptr;
+    const size_t rb = row_bytes(h);
+    char* nx = nullptr;
     float* nn = nullptr;
-    HIP_TRY(hipMalloc(&nx, (size_t)want * h->dp * sizeof(float)));
+    HIP_TRY(hipMalloc(&nx, (size_t)want * rb));
     hipError_t e = hipMalloc(&nn, (size_t)want * sizeof(float));
     if (e != hipSuccess) {
         (void)hipFree(nx);
         return fail(ISE_E_NOMEM, std::string("hipMalloc(norms): ") + hipGetErrorString(e));
     }
     if (h->n > 0) {
-        HIP_TRY(hipMemcpyAsync(nx, h->xb, (size_t)h->n * h->dp * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(nx, h->xb, (size_t)h->n * rb, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(nn, h->norms, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    HIP_TRY(hipMemsetAsync(nx + (size_t)h->n * h->dp, 0, (size_t)(want - h->n) * h->dp * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(nx + (size_t)h->n * rb, 0, (size_t)(want - h->n) * rb, st));
     HIP_TRY(hipMemsetAsync(nn + h->n, 0, (size_t)(want - h->n) * sizeof(float), st));
     HIP_TRY(hipStreamSynchronize(st));
     if (h->xb) (void)hipFree(h->xb);
@@ -1027,23 +1140,37 @@ static int reserve_rows(ise_index* h, long long need, hipStream_t st) {
     return ISE_OK;
 }
 
+// true when float32 rows can be copied verbatim into the index layout
+static bool rows_copy_verbatim(const ise_index* h) { return h->storage == ISE_STORE_F32 && h->dp == h->d; }
+
+static void launch_norms(ise_index* h, long long row0, long long n, hipStream_t st) {
+    const long long nblk = (n + 3) / 4;  // n < 2^32 so nblk fits the 32-bit grid
+    if (h->storage == ISE_STORE_BF16)
+        hipLaunchKernelGGL(norms_bf16_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const __bf16*)h->xb, row0, n,
+                           h->dp, h->norms);
+    else
+        hipLaunchKernelGGL(norms_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)h->xb, row0, n, h->dp,
+                           h->norms);
+}
+
 static int add_device_locked(ise_index* h, const float* x_dev, long long n, hipStream_t st) {
     if (n == 0) return ISE_OK;
     if (h->n + n >= (1ll << 32)) return fail(ISE_E_INVALID, "index would exceed 2^32 - 1 rows");
     int rc = reserve_rows(h, h->n + n, st);
     if (rc) return rc;
-    float* dst = h->xb + (size_t)h->n * h->dp;
-    if (h->dp == h->d) {
+    char* dst = static_cast<char*>(h->xb) + (size_t)h->n * row_bytes(h);
+    if (rows_copy_verbatim(h)) {
         HIP_TRY(hipMemcpyAsync(dst, x_dev, (size_t)n * h->d * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
         const long long total = n * h->dp;
         const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
-        hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, st, x_dev, n, h->d, dst, h->dp);
+        if (h->storage == ISE_STORE_BF16)
+            hipLaunchKernelGGL(pad_rows_bf16_kernel, dim3(blocks), dim3(256), 0, st, x_dev, n, h->d, (__bf16*)dst, h->dp);
+        else
+            hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, st, x_dev, n, h->d, (float*)dst, h->dp);
         HIP_TRY(hipGetLastError());
     }
-    const long long nblk = (n + 3) / 4;
-    // grid.x is a 32-bit quantity; n < 2^32 so nblk < 2^30
-    hipLaunchKernelGGL(norms_kernel, dim3((unsigned)nblk), dim3(256), 0, st, h->xb, h->n, n, h->dp, h->norms);
+    launch_norms(h, h->n, n, st);
     HIP_TRY(hipGetLastError());
     h->n += n;
     return ISE_OK;
@@ -1066,20 +1193,18 @@ extern "C" int ise_index_add_host(ise_index_t* h, const float* x, int64_t n) {
     if (h->n + n >= (1ll << 32)) return fail(ISE_E_INVALID, "index would exceed 2^32 - 1 rows");
     int rc = reserve_rows(h, h->n + n, h->stream);
     if (rc) return rc;
-    // upload in slabs through a device staging buffer (only needed when padding)
+    // upload in slabs; a device staging buffer is needed when rows are padded or converted
     const long long slab = std::max<long long>(1, (256ll << 20) / ((long long)h->d * 4));
     float* tmp = nullptr;
-    if (h->dp != h->d) HIP_TRY(hipMalloc(&tmp, (size_t)std::min<long long>(slab, n) * h->d * sizeof(float)));
+    if (!rows_copy_verbatim(h)) HIP_TRY(hipMalloc(&tmp, (size_t)std::min<long long>(slab, n) * h->d * sizeof(float)));
     for (long long i0 = 0; i0 < n; i0 += slab) {
         const long long m = std::min<long long>(slab, n - i0);
-        if (h->dp == h->d) {
-            float* dst = h->xb + (size_t)h->n * h->dp;
+        if (rows_copy_verbatim(h)) {
+            char* dst = static_cast<char*>(h->xb) + (size_t)h->n * row_bytes(h);
             hipError_t e = hipMemcpyAsync(dst, x + (size_t)i0 * h->d, (size_t)m * h->d * sizeof(float),
                                           hipMemcpyHostToDevice, h->stream);
             if (e != hipSuccess) return fail(ISE_E_HIP, std::string("H2D: ") + hipGetErrorString(e));
-            const long long nblk = (m + 3) / 4;
-            hipLaunchKernelGGL(norms_kernel, dim3((unsigned)nblk), dim3(256), 0, h->stream, h->xb, h->n, m,
-                               h->dp, h->norms);
+            launch_norms(h, h->n, m, h->stream);
             h->n += m;
         } else {
             hipError_t e = hipMemcpyAsync(tmp, x + (size_t)i0 * h->d, (size_t)m * h->d * sizeof(float),
@@ -1110,42 +1235,68 @@ extern "C" int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n,
     if (n == 0) return ISE_OK;
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard gd(h->device);
-    HIP_TRY(hipMemcpy2DAsync(out, (size_t)h->d * 4, h->xb + (size_t)i0 * h->dp, (size_t)h->dp * 4, (size_t)h->d * 4,
-                             (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    return ISE_OK;
+    const char* src = static_cast<const char*>(h->xb) + (size_t)i0 * row_bytes(h);
+    if (h->storage == ISE_STORE_F32) {
+        HIP_TRY(hipMemcpy2DAsync(out, (size_t)h->d * 4, src, row_bytes(h), (size_t)h->d * 4, (size_t)n,
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return ISE_OK;
+    }
+    // bf16 rows come back as the float32 values they hold, in slabs through a device buffer
+    const long long slab = std::max<long long>(1, (64ll << 20) / ((long long)h->d * 4));
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)std::min<long long>(slab, n) * h->d * sizeof(float)));
+    int rc = ISE_OK;
+    for (long long r0 = 0; r0 < n && rc == ISE_OK; r0 += slab) {
+        const long long m = std::min<long long>(slab, n - r0);
+        const long long total = m * h->d;
+        hipLaunchKernelGGL(unpack_rows_bf16_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)),
+                           dim3(256), 0, h->stream, (const __bf16*)(src + (size_t)r0 * row_bytes(h)), m, h->d, h->dp, tmp);
+        hipError_t e = hipMemcpyAsync(out + (size_t)r0 * h->d, tmp, (size_t)total * sizeof(float), hipMemcpyDeviceToHost,
+                                      h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(ISE_E_HIP, std::string("reconstruct: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(tmp);
+    return rc;
 }
 
 // ---- search
 #define LDS_LIMIT (160 * 1024)
-template <int CH, int W, int T>
+template <int CH, int W, int T, bool BF16>
 static void launch_one(dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     static bool attr_done = false;  // benign race: the attribute is idempotent
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CH, W, T>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CH, W, T, BF16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr_done = true;
     }
-    hipLaunchKernelGGL((scan_kernel<CH, W, T>), grid, dim3(W * 64), lds, st, sp);
+    hipLaunchKernelGGL((scan_kernel<CH, W, T, BF16>), grid, dim3(W * 64), lds, st, sp);
 }
-template <int W, int T>
+template <int W, int T, bool BF16>
 static void launch_scan_ch(int ch, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     switch (ch) {
-        case 8: launch_one<8, W, T>(grid, lds, st, sp); break;
-        case 4: launch_one<4, W, T>(grid, lds, st, sp); break;
-        case 2: launch_one<2, W, T>(grid, lds, st, sp); break;
-        default: launch_one<1, W, T>(grid, lds, st, sp); break;
+        case 8: launch_one<8, W, T, BF16>(grid, lds, st, sp); break;
+        case 4: launch_one<4, W, T, BF16>(grid, lds, st, sp); break;
+        case 2: launch_one<2, W, T, BF16>(grid, lds, st, sp); break;
+        default: launch_one<1, W, T, BF16>(grid, lds, st, sp); break;
     }
 }
-template <int W>
+template <int W, bool BF16>
 static void launch_scan_w(int ch, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
-    if (T == 1) launch_scan_ch<W, 1>(ch, grid, lds, st, sp);
-    else if (T == 2) launch_scan_ch<W, 2>(ch, grid, lds, st, sp);
-    else launch_scan_ch<W, 3>(ch, grid, lds, st, sp);
+    if (T == 1) launch_scan_ch<W, 1, BF16>(ch, grid, lds, st, sp);
+    else if (T == 2) launch_scan_ch<W, 2, BF16>(ch, grid, lds, st, sp);
+    else launch_scan_ch<W, 3, BF16>(ch, grid, lds, st, sp);
 }
-static void launch_scan(int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
-    if (waves == 8) launch_scan_w<8>(ch, T, grid, lds, st, sp);
-    else launch_scan_w<4>(ch, T, grid, lds, st, sp);
+static void launch_scan(bool bf16, int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st,
+                        const ScanParams& sp) {
+    if (bf16) {
+        if (waves == 8) launch_scan_w<8, true>(ch, T, grid, lds, st, sp);
+        else launch_scan_w<4, true>(ch, T, grid, lds, st, sp);
+    } else {
+        if (waves == 8) launch_scan_w<8, false>(ch, T, grid, lds, st, sp);
+        else launch_scan_w<4, false>(ch, T, grid, lds, st, sp);
+    }
 }
 
 struct ScanPlan {
@@ -1158,11 +1309,11 @@ struct ScanPlan {
 static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     pl->kpass = k < KPASS_MAX ? k : KPASS_MAX;
     pl->kb = pl->kpass <= 16 ? 16 : 32;
-    pl->ch = chunk_steps(h->dp);
+    pl->ch = chunk_steps(h);
 #ifdef ISE_ABLATE
     if (const char* e = getenv("ISE_CH")) {  // dev: force a smaller chunk (must divide dp/16)
         const int ch = atoi(e);
-        if ((ch == 1 || ch == 2 || ch == 4 || ch == 8) && (h->dp / 16) % ch == 0) pl->ch = ch;
+        if ((ch == 1 || ch == 2 || ch == 4 || ch == 8) && (int)(row_bytes(h) / 64) % ch == 0) pl->ch = ch;
     }
 #endif
     // relative time of one pass over the index with T query tiles (measured, 1M x 512)
@@ -1177,7 +1328,7 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
         int wv = 0;
         size_t lds = 0;
         for (int cand_w = 8; cand_w >= 4 && !wv; cand_w -= 4) {
-            lds = scan_lds_bytes(h->dp, cand_w, t, pl->kb);
+            lds = scan_lds_bytes(h, cand_w, t, pl->kb);
             if (lds <= LDS_LIMIT) wv = cand_w;
         }
         if (!wv) break;
@@ -1200,7 +1351,7 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
         int wv = 8, bpc = 2;
         if (pl->T == 1 && sscanf(e, "%d,%d", &wv, &bpc) == 2 && (wv == 4 || wv == 8) && bpc >= 1) {
             pl->waves = wv;
-            pl->lds = scan_lds_bytes(h->dp, wv, 1, pl->kb);
+            pl->lds = scan_lds_bytes(h, wv, 1, pl->kb);
             blocks_per_cu = bpc;
         }
     }
@@ -1293,7 +1444,8 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
 
     ScanParams sp;
     sp.xb = h->xb; sp.norms = h->norms; sp.q = q_dev; sp.floor_keys = nullptr; sp.part = w->part;
-    sp.n = h->n; sp.d = h->d; sp.dp = h->dp; sp.qs_stride = qs_stride_for(h->dp);
+    sp.n = h->n; sp.d = h->d; sp.dp = h->dp; sp.qs_stride = qs_stride_for(h);
+    sp.row_slots = (int)(row_bytes(h) / 16);
     sp.nq = (int)nq; sp.k = pl.kpass; sp.kb = pl.kb; sp.metric = h->metric; sp.id_base = id_base;
     sp.tiles_total = pl.tiles_total; sp.tiles_per_block = pl.tiles_per_block;
     sp.ablate = 0;
@@ -1313,7 +1465,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     if (k <= pl.kpass) {
         mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out;
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
-        launch_scan(pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
+        launch_scan(h->storage == ISE_STORE_BF16, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
@@ -1329,7 +1481,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     for (int off = 0; off < k; off += pl.kpass) {
         sp.floor_keys = off ? floor_dev : nullptr;
         mp.D = nullptr; mp.I = nullptr; mp.keys_out = pass_keys;
-        launch_scan(pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
+        launch_scan(h->storage == ISE_STORE_BF16, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
         HIP_TRY(hipGetLastError());

@@ -59,20 +59,27 @@ class IndexFlat:
     backend/descriptors.py:125); the GIL is released while the device works.
     """
 
-    def __init__(self, d: int, metric: int = METRIC_L2, device: int | None = None):
+    def __init__(self, d: int, metric: int = METRIC_L2, device: int | None = None, storage: str = "f32"):
+        """``storage="bf16"`` (extension, not a Faiss IndexFlat feature) keeps rows as bf16 and
+        rounds queries to bf16 too: approximate results at half the HBM traffic (BASELINE config 5)."""
         self.d = int(d)
         self.metric_type = int(metric)
         self.is_trained = True
+        self.storage = storage
         self.device = _default_device() if device is None else int(device)
         self._h = ctypes.c_void_p()
         self._lock = threading.Lock()
-        _n.check(_n.lib.ise_index_create(ctypes.byref(self._h), self.d, self.metric_type, self.device))
+        store = {"f32": _n.STORE_F32, "bf16": _n.STORE_BF16}[storage]
+        _n.check(_n.lib.ise_index_create_ex(ctypes.byref(self._h), self.d, self.metric_type, self.device, store))
 
     # -- lifetime
     def __del__(self):
         h = getattr(self, "_h", None)
         if h is not None and h.value:
-            _n.lib.ise_index_destroy(h)
+            try:
+                _n.lib.ise_index_destroy(h)
+            except Exception:  # interpreter shutdown: module globals may already be gone
+                pass
             h.value = None
 
     @property
@@ -169,13 +176,13 @@ class IndexFlat:
 
 
 class IndexFlatL2(IndexFlat):
-    def __init__(self, d: int, device: int | None = None):
-        super().__init__(d, METRIC_L2, device)
+    def __init__(self, d: int, device: int | None = None, storage: str = "f32"):
+        super().__init__(d, METRIC_L2, device, storage)
 
 
 class IndexFlatIP(IndexFlat):
-    def __init__(self, d: int, device: int | None = None):
-        super().__init__(d, METRIC_INNER_PRODUCT, device)
+    def __init__(self, d: int, device: int | None = None, storage: str = "f32"):
+        super().__init__(d, METRIC_INNER_PRODUCT, device, storage)
 
 
 def merge_keys_torch(keys, metric: int):

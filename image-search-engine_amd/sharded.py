@@ -19,11 +19,11 @@ import torch.distributed as dist
 class HipShardBackend:
     """Shard-local compute on the MI355X through include/ise_knn.h."""
 
-    def __init__(self, d: int, metric: int, device: int | None = None):
+    def __init__(self, d: int, metric: int, device: int | None = None, storage: str = "f32"):
         from . import faiss_compat as fc
 
         self._fc = fc
-        self.index = fc.IndexFlat(d, metric, device)
+        self.index = fc.IndexFlat(d, metric, device, storage)
         self.metric = metric
         self.device = torch.device("cuda", self.index.device)
 
@@ -47,11 +47,11 @@ class HipShardBackend:
 class ShardedIndexFlat:
     """IndexFlat whose rows are split over the ranks of a process group."""
 
-    def __init__(self, d: int, metric: int, group=None, backend=None):
+    def __init__(self, d: int, metric: int, group=None, backend=None, storage: str = "f32"):
         self.d, self.metric_type, self.group = int(d), int(metric), group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.backend = backend if backend is not None else HipShardBackend(d, metric)
+        self.backend = backend if backend is not None else HipShardBackend(d, metric, storage=storage)
         self.id_base = 0
         self._counts = [0] * self.world
 

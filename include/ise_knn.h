@@ -40,6 +40,10 @@ extern "C" {
 #define ISE_METRIC_INNER_PRODUCT 0 /* faiss.METRIC_INNER_PRODUCT */
 #define ISE_METRIC_L2 1            /* faiss.METRIC_L2 */
 
+#define ISE_STORE_F32 0  /* index rows kept as float32: exact results */
+#define ISE_STORE_BF16 1 /* index rows (and queries) rounded to bf16, fp32 accumulation: approximate,
+                            half the HBM traffic (BASELINE config 5: cosine over normalised rows) */
+
 #define ISE_OK 0
 #define ISE_E_INVALID -1  /* bad argument (shape, k, NULL) */
 #define ISE_E_HIP -2      /* HIP runtime error (message has the hipError string) */
@@ -60,6 +64,8 @@ int ise_device_arch(int device, char* buf, int buflen);
 /* index lifetime: replaces faiss.IndexFlatL2(d) / faiss.IndexFlatIP(d)
  * (backend/utils.py:302,306; backend/siamese/siamese_pt/create_index.py:40). */
 int ise_index_create(ise_index_t** out, int d, int metric, int device);
+/* same with an explicit row storage type (ISE_STORE_*); not a Faiss IndexFlat feature */
+int ise_index_create_ex(ise_index_t** out, int d, int metric, int device, int storage);
 int ise_index_destroy(ise_index_t* h);
 int ise_index_reset(ise_index_t* h); /* drop all rows, keep d/metric */
 int ise_index_info(const ise_index_t* h, int* d, int* metric, int64_t* ntotal, int* device);

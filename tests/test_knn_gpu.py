@@ -311,3 +311,33 @@ def test_full_size_properties(faiss):
     keys = torch.stack([a.search_keys_torch(xq, k, 0), b.search_keys_torch(xq, k, half)])
     D2, I2 = faiss.merge_keys_torch(keys, L2)
     assert torch.equal(I2, I) and torch.equal(D2, D)
+
+
+def _bf16_round(x):
+    import torch
+
+    return torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+@pytest.mark.parametrize("n,d,nq,k", [(20_000, 512, 16, 10), (5_000, 100, 40, 5), (3_000, 2048, 3, 20)])
+def test_bf16_storage_matches_oracle_on_rounded_data(faiss, metric, n, d, nq, k):
+    """BASELINE config 5 path: rows and queries rounded to bf16, fp32 accumulation.  Against the
+    exact oracle evaluated on the SAME rounded values only the summation order differs."""
+    rng = np.random.default_rng(n + d + k + metric)
+    xb = rng.standard_normal((n, d)).astype(np.float32)
+    xq = rng.standard_normal((nq, d)).astype(np.float32)
+    if metric == IP:  # cosine: normalised rows (backend/utils.py:300-303)
+        xb /= np.linalg.norm(xb, axis=1, keepdims=True)
+        xq /= np.linalg.norm(xq, axis=1, keepdims=True)
+    index = faiss.IndexFlat(d, metric, storage="bf16")
+    index.add(xb)
+    D, I = index.search(xq, k)
+    xb_r, xq_r = _bf16_round(xb), _bf16_round(xq)
+    D_ref, I_ref = ko.knn_exact(xb_r, xq_r, k, metric)
+    assert_knn_matches(D, I, D_ref, I_ref, xb_r, xq_r, metric, gap=ko.kth_gap(xb_r, xq_r, k, metric))
+    assert np.array_equal(index.reconstruct_n(0, 50), xb_r[:50])  # the index holds the rounded rows
+    # recall against the unrounded exact answer is what config 5 reports
+    _, I_exact = ko.knn_exact(xb, xq, k, metric)
+    recall = np.mean([len(set(I[q]) & set(I_exact[q])) / k for q in range(nq)])
+    assert recall >= 0.7, recall
