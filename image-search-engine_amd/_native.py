@@ -48,6 +48,7 @@ PROTOTYPES = [
     ("ise_index_search_host", _int, [_vp, _vp, _i64, _int, _vp, _vp]),
     ("ise_index_search_device", _int, [_vp, _vp, _i64, _int, _vp, _vp, _vp]),
     ("ise_index_search_keys_device", _int, [_vp, _vp, _i64, _int, ctypes.c_uint32, _vp, _vp]),
+    ("ise_index_assign_device", _int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     ("ise_merge_keys_device", _int, [_vp, _int, _i64, _int, _int, _vp, _vp, _int, _vp]),
     ("ise_normalize_rows_device", _int, [_vp, _i64, _int, _int, _vp]),
     ("ise_normalize_rows_host", _int, [_vp, _i64, _int, _int]),

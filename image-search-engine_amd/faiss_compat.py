@@ -114,6 +114,27 @@ class IndexFlat:
         return out
 
     # -- query side
+    ASSIGN_MIN_NQ = 2048  # k = 1 searches with at least this many rows use the assignment kernel
+
+    def _assign_applies(self, nq: int, k: int) -> bool:
+        return (k == 1 and nq >= self.ASSIGN_MIN_NQ and self.storage == "f32" and self.d <= 512
+                and 0 < self.ntotal <= 65536)
+
+    def assign_torch(self, x):
+        """Nearest index row of every row of ``x`` (CUDA float32 (n, d)): the k = 1 search of
+        FaissKMeans.transform (backend/kmeans_faiss.py:49) as one MFMA-bound kernel.
+        Returns CUDA (D float32 (n, 1), I int64 (n, 1))."""
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == self.d
+        x = x.contiguous()
+        n = x.shape[0]
+        D = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+        I = torch.empty((n, 1), dtype=torch.int64, device=x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        _n.check(_n.lib.ise_index_assign_device(self._h, x.data_ptr(), n, D.data_ptr(), I.data_ptr(), st))
+        return D, I
+
     def search(self, x, k: int):
         """(D float32 (nq,k), I int64 (nq,k)), fresh arrays.  L2: squared distance
         ascending; IP: descending; unfilled slots -1 / +-FLT_MAX."""
@@ -121,6 +142,18 @@ class IndexFlat:
         k = int(k)
         assert k > 0
         nq = x.shape[0]
+        if self._assign_applies(nq, k):
+            import torch
+
+            D = np.empty((nq, 1), dtype=np.float32)
+            I = np.empty((nq, 1), dtype=np.int64)
+            dev = torch.device("cuda", self.device)
+            step = max(1, (1 << 28) // (4 * self.d))  # 256 MiB of rows per upload
+            for i0 in range(0, nq, step):
+                d_, i_ = self.assign_torch(torch.from_numpy(x[i0:i0 + step]).to(dev))
+                D[i0:i0 + step] = d_.cpu().numpy()
+                I[i0:i0 + step] = i_.cpu().numpy()
+            return D, I
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
         _n.check(_n.lib.ise_index_search_host(self._h, x.ctypes.data, nq, k, D.ctypes.data, I.ctypes.data))

@@ -103,6 +103,14 @@ int ise_index_search_keys_device(ise_index_t* h, const float* q_dev, int64_t nq,
 int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int64_t nq, int k,
                           int metric, float* D_dev, int64_t* I_dev, int device, void* stream);
 
+/* index.search(X, 1) for MANY rows against a SMALL index: nearest-centroid assignment,
+ * FaissKMeans.transform (backend/kmeans_faiss.py:46-50; BASELINE config 4).  X: n x d
+ * float32 on the device; I: n int64 (row of the best index entry, -1 if none); D: n
+ * float32 or NULL (squared L2 / inner product of the best entry).  MFMA-bound GEMM-shaped
+ * kernel; needs a float32 index with d <= 512 (otherwise use ise_index_search_*). */
+int ise_index_assign_device(ise_index_t* h, const float* x_dev, int64_t n, float* D_dev,
+                            int64_t* I_dev, void* stream);
+
 /* faiss.normalize_L2(x) (backend/utils.py:303, backend/engine.py:53,
  * backend/siamese/test_index.py:53, siamese_pt/create_index.py:57,
  * siamese_tf/create_index.py:54):

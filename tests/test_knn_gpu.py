@@ -341,3 +341,30 @@ def test_bf16_storage_matches_oracle_on_rounded_data(faiss, metric, n, d, nq, k)
     _, I_exact = ko.knn_exact(xb, xq, k, metric)
     recall = np.mean([len(set(I[q]) & set(I_exact[q])) / k for q in range(nq)])
     assert recall >= 0.7, recall
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+@pytest.mark.parametrize("n,K,d", [(5000, 256, 128), (4099, 1000, 32), (3001, 200, 64), (2500, 77, 100), (2100, 4096, 128),
+                                   (2048, 130, 512)])
+def test_assignment_kernel_matches_oracle(faiss, metric, n, K, d):
+    """k = 1 nearest-centroid assignment (backend/kmeans_faiss.py:46-50, BASELINE config 4 shape):
+    SIFT-valued rows against unit-norm centroids through the dedicated MFMA kernel."""
+    import torch
+
+    rng = np.random.default_rng(n + K + d + metric)
+    cent = ko.normalize_rows(rng.standard_normal((K, d)).astype(np.float32))
+    X = rng.integers(0, 256, (n, d)).astype(np.float32)
+    index = make_index(faiss, metric, d)
+    index.add(cent)
+    assert index._assign_applies(n, 1)
+    D, I = index.search(X, 1)  # routed to the assignment kernel (n >= ASSIGN_MIN_NQ)
+    D_ref, I_ref = ko.knn_exact(cent, X, 1, metric)
+    assert_knn_matches(D, I, D_ref, I_ref, cent, X, metric, gap=ko.kth_gap(cent, X, 1, metric), rtol=2e-4)
+    # the general scan path agrees (it is what smaller batches use)
+    Ds, Is = index.search(X[:64], 1)
+    assert_knn_matches(Ds, Is, D_ref[:64], I_ref[:64], cent, X[:64], metric, rtol=2e-4)
+    # duplicate centroids: the lower id wins
+    dup = make_index(faiss, metric, d)
+    dup.add(np.concatenate([cent[:5], cent[:5]]))
+    Dd, Id = dup.assign_torch(torch.from_numpy(X[:300]).cuda())
+    assert (Id.cpu().numpy() < 5).all()
