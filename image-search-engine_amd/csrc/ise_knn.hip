@@ -103,6 +103,7 @@ struct ScanParams {
     const void* xb;      // [cap][dp] float32 or bf16 rows; 16-byte "slots": row_slots per row
     const float* norms;  // [cap]
     const float* q;      // [nq][d]
+    const float* mu;     // [dp] shift vector (zero padded), used by SHIFT kernels
     const u64* floor_keys;  // optional [nq]: only keys > floor enter (k > 64 passes)
     u64* part;           // [nqt][nb][16 T][k]
     long long n;         // rows in the index
@@ -296,7 +297,8 @@ __device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, i
 
 // LDS bytes of one scan block (host and device agree through this function)
 __host__ __device__ constexpr size_t scan_lds_layout(int S, int waves, int T, int kb) {
-    return (size_t)(16 * T) * ((size_t)S * 4 + 4 /* qs, xn */ + 8 /* tauS */ + 8 /* bwc, lockS */ +
+    return (size_t)S * 4 /* mus: the shift vector, laid out like one query row */ +
+           (size_t)(16 * T) * ((size_t)S * 4 + 4 /* qs, xn */ + 8 /* tauS */ + 8 /* bwc, lockS */ +
                                (size_t)waves * 4 /* cntS */ + (size_t)kb * 8 /* bootw */ +
                                (size_t)waves * CAP * 8 /* cand; boot staging aliases it */);
 }
@@ -318,8 +320,17 @@ __host__ __device__ constexpr size_t scan_lds_layout(int S, int waves, int T, in
 //          key, so tauS tracks the block's running k-th best.
 //   final  one wave selects the exact sorted top-k of bootw + what is left in the W
 //          private lists and writes the block's list to HBM.
-template <int CH, int W, int T, bool BF16>
+//
+// SHIFT (fp32 L2 only): distances are translation invariant, and the expanded form
+// |x|^2 + |y|^2 - 2 x.y loses digits when the rows share a large common component
+// (CNN embeddings: |y|^2 ~ 1e5, neighbour distances ~ 1e-1).  The index keeps a fixed
+// shift vector mu (mean of the first rows added); norms are |y - mu|^2, queries are
+// staged as x - mu and the row fragments are shifted in registers before the MFMAs
+// (4 VALU subs per k-step), so every term is as small as the data's spread, not its
+// offset.  Rows stay stored unshifted (reconstruct / write_index are exact).
+template <int CH, int W, int T, bool BF16, bool SHIFT>
 __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) void scan_kernel(const ScanParams p) {
+    static_assert(!(BF16 && SHIFT), "the shift is applied to fp32 rows only");
     constexpr int BLOCK_THREADS = W * 64;
     constexpr int NQ = 16 * T;                        // queries per block pass
     constexpr int TPR = BLOCK_THREADS / 16;           // threads staging one query row (per tile)
@@ -329,7 +340,8 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     extern __shared__ __align__(16) unsigned char smem[];
     const int S = p.qs_stride;
     const int kb = p.kb;
-    float* qs = reinterpret_cast<float*>(smem);                 // [NQ][S]
+    float* mus = reinterpret_cast<float*>(smem);                // [S] shift vector (SHIFT only)
+    float* qs = mus + S;                                        // [NQ][S]
     float* xn = qs + NQ * S;                                    // [NQ]
     u64* tauS = reinterpret_cast<u64*>(xn + NQ);                // [NQ]
     int* bwc = reinterpret_cast<int*>(tauS + NQ);               // [NQ]
@@ -374,6 +386,15 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     const bool vec_q = (p.d & (BF16 ? 7 : 3)) == 0 && ((reinterpret_cast<uintptr_t>(p.q) & 15) == 0) &&
                        S4 <= TPR * QVS;
     f32x4 qv[T][QV];
+    f32x4 muv[SHIFT ? QVS : 1];
+    if (SHIFT && vec_q) {
+#pragma unroll
+        for (int i = 0; i < QVS; i++) {
+            const int j4 = tid % TPR + i * TPR;
+            muv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (j4 < dslots) muv[i] = *reinterpret_cast<const f32x4*>(p.mu + 4 * j4);
+        }
+    }
     if (vec_q) {
 #pragma unroll
         for (int tq = 0; tq < T; tq++) {
@@ -446,7 +467,11 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
                             sn = fmaf(r1, r1, sn);
                         }
                     } else {
-                        const f32x4 v = qv[tq][i];
+                        f32x4 v = qv[tq][i];
+                        if (SHIFT) {
+                            if (cc < nqt) v = v - muv[i];  // padding rows stay zero
+                            if (cc == 0) *reinterpret_cast<f32x4*>(mus + 4 * j4) = muv[i];
+                        }
                         *reinterpret_cast<f32x4*>(qs + cc * S + 4 * j4) = v;
                         sn = fmaf(v[0], v[0], sn);
                         sn = fmaf(v[1], v[1], sn);
@@ -467,8 +492,10 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
                     sn = fmaf(r0, r0, sn);
                     sn = fmaf(r1, r1, sn);
                 } else {
-                    const float v = (rowok && j < p.d) ? src[j] : 0.f;
+                    const float m = (SHIFT && j < p.d) ? p.mu[j] : 0.f;
+                    const float v = (rowok && j < p.d) ? src[j] - m : 0.f;
                     qs[cc * S + j] = v;
+                    if (SHIFT && cc == 0) mus[j] = m;
                     sn = fmaf(v, v, sn);
                 }
             }
@@ -656,6 +683,8 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
         for (int s = 0; s < CH; s++) {
             f32x4 bnext[T];
             load_b(bnext, s + 1 < CH ? s0 + s + 1 : next_first_step);
+            f32x4 as = a[s];
+            if (SHIFT) as = as - *reinterpret_cast<const f32x4*>(mus + 4 * g + 16 * (s0 + s));
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 if (BF16) {  // one 16x16x32 bf16 MFMA per k-step (8 bf16 per lane and operand)
@@ -663,10 +692,10 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
                     if (s & 1) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc1[t], 0, 0, 0);
                     else acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc0[t], 0, 0, 0);
                 } else {     // four 16x16x4 fp32 MFMAs per k-step (exact fp32 fmaf chains)
-                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], bcur[t][0], acc0[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], bcur[t][1], acc1[t], 0, 0, 0);
-                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], bcur[t][2], acc0[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], bcur[t][3], acc1[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[0], bcur[t][0], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[1], bcur[t][1], acc1[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[2], bcur[t][2], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[3], bcur[t][3], acc1[t], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -761,7 +790,8 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
 struct AssignParams {
     const float* x;      // [n][d] rows to assign (unpadded)
     const float* cb;     // [K][dp] centroids, padded rows (the index's xb)
-    const float* cnorm;  // [K] |c|^2
+    const float* cnorm;  // [K] |c|^2, or |c - mu|^2 when the index is shifted
+    const float* mu;     // [dp] the index's shift vector or null: x and c are both shifted by it
     long long n;
     int d, dp, cs_stride, K, metric;
     int cs;        // centroids per LDS stage, a multiple of 16
@@ -807,6 +837,7 @@ __global__ __launch_bounds__(512, 2) void assign_kernel(const AssignParams p) {
                     for (int e = 0; e < 4; e++)
                         if (col + e < p.d) v[e] = xr[col + e];
                 }
+                if (p.mu) v = v - *reinterpret_cast<const f32x4*>(p.mu + col);  // mu is zero beyond d, like v
                 A[xt][s] = v;
                 xnp[xt] = fmaf(v[0], v[0], xnp[xt]);
                 xnp[xt] = fmaf(v[1], v[1], xnp[xt]);
@@ -830,7 +861,10 @@ __global__ __launch_bounds__(512, 2) void assign_kernel(const AssignParams p) {
             for (int i = tid; i < CS * (p.dp >> 2); i += 512) {
                 const int cr = i / (p.dp >> 2), j4 = i - cr * (p.dp >> 2);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (c0 + cr < p.K) v = *reinterpret_cast<const f32x4*>(p.cb + (size_t)(c0 + cr) * p.dp + 4 * j4);
+                if (c0 + cr < p.K) {
+                    v = *reinterpret_cast<const f32x4*>(p.cb + (size_t)(c0 + cr) * p.dp + 4 * j4);
+                    if (p.mu) v = v - *reinterpret_cast<const f32x4*>(p.mu + 4 * j4);
+                }
                 *reinterpret_cast<f32x4*>(cs + cr * S + 4 * j4) = v;
             }
             if (tid < CS) cn[tid] = c0 + tid < p.K ? p.cnorm[c0 + tid] : 0.f;
@@ -984,14 +1018,16 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
 // |y|^2 per row, wave per row, fixed summation order (lanes stride float4, then
 // an xor butterfly): deterministic for a given dp.
 __global__ __launch_bounds__(256) void norms_kernel(const float* __restrict__ x, long long row0,
-                                                    long long n, int dp, float* __restrict__ out) {
+                                                    long long n, int dp, const float* __restrict__ mu,
+                                                    float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const long long r = row0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= row0 + n) return;
     const float* xr = x + (size_t)r * dp;
     float s = 0.f;
     for (int j = lane * 4; j < dp; j += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + j);
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + j);
+        if (mu) v = v - *reinterpret_cast<const f32x4*>(mu + j);  // |y - mu|^2 (padding columns: 0 - 0)
         s = fmaf(v[0], v[0], s);
         s = fmaf(v[1], v[1], s);
         s = fmaf(v[2], v[2], s);
@@ -999,6 +1035,23 @@ __global__ __launch_bounds__(256) void norms_kernel(const float* __restrict__ x,
     }
     s = wave_sum_f32(s);
     if (lane == 0) out[r] = s;
+}
+
+// mean of the first `rows` rows per column (d columns of a padded row), summed in row
+// order by one thread per column: deterministic, so every index built from the same
+// leading rows gets the same shift vector
+__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ x, long long rows, int d, int dp,
+                                                       float* __restrict__ mu) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= dp) return;
+    float s = 0.f;
+    if (j < d)
+        for (long long r = 0; r < rows; r++) {
+            const float v = x[(size_t)r * dp + j];
+            if (fabsf(v) <= FLT_MAX) s += v;  // NaN / inf entries must not poison every distance
+        }
+    const float m = s / (float)rows;
+    mu[j] = (j < d && fabsf(m) <= FLT_MAX) ? m : 0.f;
 }
 
 // |y|^2 of bf16 rows (the values the bf16 scan multiplies), fp32 accumulation
@@ -1109,6 +1162,8 @@ struct ise_index {
     long long n = 0, cap = 0;
     void* xb = nullptr;
     float* norms = nullptr;
+    float* mu = nullptr;       // [dp] shift vector (fp32 L2 only), zero until shift_set
+    bool shift_set = false;    // fixed once: at the first add, or by ise_index_set_shift before it
     // workspaces (grown lazily, guarded by mu): calls rotate through NWS slots and a
     // slot's reuse is ordered behind its previous use with an event, so searches on
     // different streams may be in flight together
@@ -1129,7 +1184,7 @@ struct ise_index {
     float* D_dev = nullptr;  long long* I_dev = nullptr;  size_t out_elems = 0;
     float* h_stage = nullptr;  size_t h_stage_bytes = 0;  // pinned
     int num_cu = 256;
-    std::mutex mu;
+    std::mutex mu_;
 };
 
 // rows are padded to whole k-steps of 64 bytes (16 floats / 32 bf16); rows longer than
@@ -1213,9 +1268,13 @@ extern "C" int ise_index_create_ex(ise_index_t** out, int d, int metric, int dev
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     DeviceGuard gd(device);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&h->mu, (size_t)h->dp * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->mu, 0, (size_t)h->dp * sizeof(float));
     if (e != hipSuccess) {
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->mu) (void)hipFree(h->mu);
         delete h;
-        return fail(ISE_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        return fail(ISE_E_HIP, std::string("index setup: ") + hipGetErrorString(e));
     }
     *out = h;
     return ISE_OK;
@@ -1248,6 +1307,7 @@ extern "C" int ise_index_destroy(ise_index_t* h) {
         DeviceGuard gd(h->device);
         (void)hipDeviceSynchronize();
         free_all(h);
+        if (h->mu) (void)hipFree(h->mu);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -1256,13 +1316,15 @@ extern "C" int ise_index_destroy(ise_index_t* h) {
 
 extern "C" int ise_index_reset(ise_index_t* h) {
     if (!h) return fail(ISE_E_INVALID, "handle is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     HIP_TRY(hipDeviceSynchronize());
     if (h->xb) (void)hipFree(h->xb);
     if (h->norms) (void)hipFree(h->norms);
     h->xb = h->norms = nullptr;
     h->n = h->cap = 0;
+    h->shift_set = false;
+    HIP_TRY(hipMemset(h->mu, 0, (size_t)h->dp * sizeof(float)));
     return ISE_OK;
 }
 
@@ -1310,6 +1372,20 @@ static int reserve_rows(ise_index* h, long long need, hipStream_t st) {
 // true when float32 rows can be copied verbatim into the index layout
 static bool rows_copy_verbatim(const ise_index* h) { return h->storage == ISE_STORE_F32 && h->dp == h->d; }
 
+static bool uses_shift(const ise_index* h) { return h->storage == ISE_STORE_F32 && h->metric == ISE_METRIC_L2; }
+#define SHIFT_SAMPLE_ROWS 4096 /* the shift vector is the mean of the first rows added (at most this many) */
+
+// rows [0, n_new) have just been written at the start of an empty index: fix the shift
+static int fix_shift_from_first_rows(ise_index* h, long long n_new, hipStream_t st) {
+    if (!uses_shift(h) || h->shift_set) return ISE_OK;
+    const long long rows = std::min<long long>(n_new, SHIFT_SAMPLE_ROWS);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((h->dp + 255) / 256), dim3(256), 0, st, (const float*)h->xb, rows, h->d,
+                       h->dp, h->mu);
+    HIP_TRY(hipGetLastError());
+    h->shift_set = true;
+    return ISE_OK;
+}
+
 static void launch_norms(ise_index* h, long long row0, long long n, hipStream_t st) {
     const long long nblk = (n + 3) / 4;  // n < 2^32 so nblk fits the 32-bit grid
     if (h->storage == ISE_STORE_BF16)
@@ -1317,7 +1393,7 @@ static void launch_norms(ise_index* h, long long row0, long long n, hipStream_t 
                            h->dp, h->norms);
     else
         hipLaunchKernelGGL(norms_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)h->xb, row0, n, h->dp,
-                           h->norms);
+                           uses_shift(h) ? h->mu : (const float*)nullptr, h->norms);
 }
 
 static int add_device_locked(ise_index* h, const float* x_dev, long long n, hipStream_t st) {
@@ -1337,16 +1413,41 @@ static int add_device_locked(ise_index* h, const float* x_dev, long long n, hipS
             hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, st, x_dev, n, h->d, (float*)dst, h->dp);
         HIP_TRY(hipGetLastError());
     }
+    if (h->n == 0) {
+        rc = fix_shift_from_first_rows(h, n, st);
+        if (rc) return rc;
+    }
     launch_norms(h, h->n, n, st);
     HIP_TRY(hipGetLastError());
     h->n += n;
     return ISE_OK;
 }
 
+extern "C" int ise_index_set_shift(ise_index_t* h, const float* mu_host) {
+    if (!h || !mu_host) return fail(ISE_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu_);
+    if (!uses_shift(h)) return ISE_OK;  // only float32 L2 indexes are shifted
+    if (h->n > 0 || h->shift_set) return fail(ISE_E_INVALID, "the shift must be set before the first add");
+    DeviceGuard gd(h->device);
+    HIP_TRY(hipMemset(h->mu, 0, (size_t)h->dp * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->mu, mu_host, (size_t)h->d * sizeof(float), hipMemcpyHostToDevice));
+    h->shift_set = true;
+    return ISE_OK;
+}
+
+extern "C" int ise_index_get_shift(ise_index_t* h, float* mu_host) {
+    if (!h || !mu_host) return fail(ISE_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu_);
+    DeviceGuard gd(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(mu_host, h->mu, (size_t)h->d * sizeof(float), hipMemcpyDeviceToHost));
+    return ISE_OK;
+}
+
 extern "C" int ise_index_add_device(ise_index_t* h, const float* x_dev, int64_t n, void* stream) {
     if (!h) return fail(ISE_E_INVALID, "handle is NULL");
     if (n < 0 || (n > 0 && !x_dev)) return fail(ISE_E_INVALID, "bad rows argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     return add_device_locked(h, x_dev, n, (hipStream_t)stream);
 }
@@ -1355,7 +1456,7 @@ extern "C" int ise_index_add_host(ise_index_t* h, const float* x, int64_t n) {
     if (!h) return fail(ISE_E_INVALID, "handle is NULL");
     if (n < 0 || (n > 0 && !x)) return fail(ISE_E_INVALID, "bad rows argument");
     if (n == 0) return ISE_OK;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     if (h->n + n >= (1ll << 32)) return fail(ISE_E_INVALID, "index would exceed 2^32 - 1 rows");
     int rc = reserve_rows(h, h->n + n, h->stream);
@@ -1371,6 +1472,10 @@ extern "C" int ise_index_add_host(ise_index_t* h, const float* x, int64_t n) {
             hipError_t e = hipMemcpyAsync(dst, x + (size_t)i0 * h->d, (size_t)m * h->d * sizeof(float),
                                           hipMemcpyHostToDevice, h->stream);
             if (e != hipSuccess) return fail(ISE_E_HIP, std::string("H2D: ") + hipGetErrorString(e));
+            if (h->n == 0) {
+                rc = fix_shift_from_first_rows(h, m, h->stream);
+                if (rc) return rc;
+            }
             launch_norms(h, h->n, m, h->stream);
             h->n += m;
         } else {
@@ -1400,7 +1505,7 @@ extern "C" int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n,
     if (!h) return fail(ISE_E_INVALID, "handle is NULL");
     if (i0 < 0 || n < 0 || i0 + n > h->n || (n > 0 && !out)) return fail(ISE_E_INVALID, "row range out of bounds");
     if (n == 0) return ISE_OK;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     const char* src = static_cast<const char*>(h->xb) + (size_t)i0 * row_bytes(h);
     if (h->storage == ISE_STORE_F32) {
@@ -1430,40 +1535,39 @@ extern "C" int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n,
 
 // ---- search
 #define LDS_LIMIT (160 * 1024)
-template <int CH, int W, int T, bool BF16>
+template <int CH, int W, int T, bool BF16, bool SHIFT>
 static void launch_one(dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     static bool attr_done = false;  // benign race: the attribute is idempotent
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CH, W, T, BF16>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CH, W, T, BF16, SHIFT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr_done = true;
     }
-    hipLaunchKernelGGL((scan_kernel<CH, W, T, BF16>), grid, dim3(W * 64), lds, st, sp);
+    hipLaunchKernelGGL((scan_kernel<CH, W, T, BF16, SHIFT>), grid, dim3(W * 64), lds, st, sp);
 }
-template <int W, int T, bool BF16>
+template <int W, int T, bool BF16, bool SHIFT>
 static void launch_scan_ch(int ch, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     switch (ch) {
-        case 8: launch_one<8, W, T, BF16>(grid, lds, st, sp); break;
-        case 4: launch_one<4, W, T, BF16>(grid, lds, st, sp); break;
-        case 2: launch_one<2, W, T, BF16>(grid, lds, st, sp); break;
-        default: launch_one<1, W, T, BF16>(grid, lds, st, sp); break;
+        case 8: launch_one<8, W, T, BF16, SHIFT>(grid, lds, st, sp); break;
+        case 4: launch_one<4, W, T, BF16, SHIFT>(grid, lds, st, sp); break;
+        case 2: launch_one<2, W, T, BF16, SHIFT>(grid, lds, st, sp); break;
+        default: launch_one<1, W, T, BF16, SHIFT>(grid, lds, st, sp); break;
     }
 }
-template <int W, bool BF16>
-static void launch_scan_w(int ch, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
-    if (T == 1) launch_scan_ch<W, 1, BF16>(ch, grid, lds, st, sp);
-    else if (T == 2) launch_scan_ch<W, 2, BF16>(ch, grid, lds, st, sp);
-    else launch_scan_ch<W, 3, BF16>(ch, grid, lds, st, sp);
+// variants built: (waves, T) in {(8,1), (4,1), (8,2), (8,3)}; 4 waves exist for one query
+// tile only (long rows, where 8 waves' lists no longer fit beside the tile)
+template <bool BF16, bool SHIFT>
+static void launch_scan_v(int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
+    if (T == 1 && waves == 4) launch_scan_ch<4, 1, BF16, SHIFT>(ch, grid, lds, st, sp);
+    else if (T == 1) launch_scan_ch<8, 1, BF16, SHIFT>(ch, grid, lds, st, sp);
+    else if (T == 2) launch_scan_ch<8, 2, BF16, SHIFT>(ch, grid, lds, st, sp);
+    else launch_scan_ch<8, 3, BF16, SHIFT>(ch, grid, lds, st, sp);
 }
-static void launch_scan(bool bf16, int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st,
+static void launch_scan(const ise_index* h, int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st,
                         const ScanParams& sp) {
-    if (bf16) {
-        if (waves == 8) launch_scan_w<8, true>(ch, T, grid, lds, st, sp);
-        else launch_scan_w<4, true>(ch, T, grid, lds, st, sp);
-    } else {
-        if (waves == 8) launch_scan_w<8, false>(ch, T, grid, lds, st, sp);
-        else launch_scan_w<4, false>(ch, T, grid, lds, st, sp);
-    }
+    if (h->storage == ISE_STORE_BF16) launch_scan_v<true, false>(ch, waves, T, grid, lds, st, sp);
+    else if (uses_shift(h)) launch_scan_v<false, true>(ch, waves, T, grid, lds, st, sp);
+    else launch_scan_v<false, false>(ch, waves, T, grid, lds, st, sp);
 }
 
 struct ScanPlan {
@@ -1494,7 +1598,7 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     for (int t = 1; t <= tmax; t++) {
         int wv = 0;
         size_t lds = 0;
-        for (int cand_w = 8; cand_w >= 4 && !wv; cand_w -= 4) {
+        for (int cand_w = 8; cand_w >= (t == 1 ? 4 : 8) && !wv; cand_w -= 4) {  // 4 waves: one tile only
             lds = scan_lds_bytes(h, cand_w, t, pl->kb);
             if (lds <= LDS_LIMIT) wv = cand_w;
         }
@@ -1610,7 +1714,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     } release{w, st};
 
     ScanParams sp;
-    sp.xb = h->xb; sp.norms = h->norms; sp.q = q_dev; sp.floor_keys = nullptr; sp.part = w->part;
+    sp.xb = h->xb; sp.norms = h->norms; sp.q = q_dev; sp.mu = h->mu; sp.floor_keys = nullptr; sp.part = w->part;
     sp.n = h->n; sp.d = h->d; sp.dp = h->dp; sp.qs_stride = qs_stride_for(h);
     sp.row_slots = (int)(row_bytes(h) / 16);
     sp.nq = (int)nq; sp.k = pl.kpass; sp.kb = pl.kb; sp.metric = h->metric; sp.id_base = id_base;
@@ -1632,7 +1736,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     if (k <= pl.kpass) {
         mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out;
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
-        launch_scan(h->storage == ISE_STORE_BF16, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
+        launch_scan(h, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
@@ -1648,7 +1752,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     for (int off = 0; off < k; off += pl.kpass) {
         sp.floor_keys = off ? floor_dev : nullptr;
         mp.D = nullptr; mp.I = nullptr; mp.keys_out = pass_keys;
-        launch_scan(h->storage == ISE_STORE_BF16, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
+        launch_scan(h, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
         HIP_TRY(hipGetLastError());
@@ -1682,7 +1786,7 @@ extern "C" int ise_index_search_device(ise_index_t* h, const float* q_dev, int64
     if (rc) return rc;
     if (nq == 0) return ISE_OK;
     if (!D_dev || !I_dev) return fail(ISE_E_INVALID, "output pointer is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     return search_enqueue(h, q_dev, nq, k, 0u, D_dev, (long long*)I_dev, nullptr, (hipStream_t)stream, nullptr);
 }
@@ -1694,7 +1798,7 @@ extern "C" int ise_index_search_keys_device(ise_index_t* h, const float* q_dev, 
     if (nq == 0) return ISE_OK;
     if (!keys_dev) return fail(ISE_E_INVALID, "output pointer is NULL");
     if ((long long)id_base + h->n > (1ll << 32)) return fail(ISE_E_INVALID, "id_base + ntotal exceeds 2^32");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     return search_enqueue(h, q_dev, nq, k, id_base, nullptr, nullptr, (u64*)keys_dev, (hipStream_t)stream, nullptr);
 }
@@ -1707,7 +1811,7 @@ extern "C" int ise_index_search_timed_device(ise_index_t* h, const float* q_dev,
     if (nq == 0 || iters <= 0 || k > KPASS_MAX)
         return fail(ISE_E_INVALID, "timed search needs nq > 0, iters > 0, k <= 32");
     if (!D_dev || !I_dev) return fail(ISE_E_INVALID, "output pointer is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     hipStream_t st = (hipStream_t)stream;
     TimedOut tm;
@@ -1741,7 +1845,7 @@ extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq,
     if (rc) return rc;
     if (nq == 0) return ISE_OK;
     if (!D || !I) return fail(ISE_E_INVALID, "output pointer is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     // bounds the workspace (part + multi-pass keys); larger calls loop
     const long long batch = k <= KPASS_MAX ? 4096 : 1024;
@@ -1807,12 +1911,12 @@ extern "C" int ise_index_assign_device(ise_index_t* h, const float* x_dev, int64
     if (!h) return fail(ISE_E_INVALID, "handle is NULL");
     if (n < 0 || (n > 0 && (!x_dev || !I_dev))) return fail(ISE_E_INVALID, "bad argument");
     if (n == 0) return ISE_OK;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     if (!assign_supported(h))
         return fail(ISE_E_INVALID, "assignment kernel needs a non-empty float32 index with d <= 512");
     AssignParams ap;
-    ap.x = x_dev; ap.cb = (const float*)h->xb; ap.cnorm = h->norms; ap.n = n; ap.d = h->d; ap.dp = h->dp;
+    ap.x = x_dev; ap.cb = (const float*)h->xb; ap.cnorm = h->norms; ap.mu = uses_shift(h) ? h->mu : nullptr; ap.n = n; ap.d = h->d; ap.dp = h->dp;
     ap.cs_stride = qs_stride_for(h); ap.K = (int)h->n; ap.metric = h->metric; ap.cs = assign_stage_rows(h);
     ap.I = (long long*)I_dev; ap.D = D_dev;
     const size_t lds = assign_lds_bytes(h);

@@ -103,6 +103,18 @@ class CNNDescriptor:
 
     # -- batched entry points (new capability)
     @torch.no_grad()
+    def extract_features_tensor(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """Device-resident batch: uint8 (B, H, W, 3) BGR tensor on the extractor's device ->
+        (B, d) float32 on the device.  Same arithmetic as ``extract_features_batch`` without
+        the per-image host work (used for BASELINE config 2's synthetic images)."""
+        size = config.RESIZE_SIZE
+        x = images_u8.permute(0, 3, 1, 2).float()
+        if x.shape[2] != size or x.shape[3] != size:
+            x = F.interpolate(x, size=(size, size), mode="bilinear", align_corners=False)
+        x = ((x - self._mean) / self._std).contiguous(memory_format=torch.channels_last)
+        return self._forward(x)
+
+    @torch.no_grad()
     def extract_features_batch(self, images) -> torch.Tensor:
         """list of HWC BGR uint8 arrays -> (B, d) float32 tensor ON THE DEVICE."""
         return self._forward(self.preprocessor(images))

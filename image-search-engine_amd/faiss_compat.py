@@ -91,6 +91,18 @@ class IndexFlat:
     def reset(self) -> None:
         _n.check(_n.lib.ise_index_reset(self._h))
 
+    # float32 L2 indexes evaluate distances around a fixed shift vector (see include/ise_knn.h);
+    # shards of one logical index share it
+    def get_shift(self) -> np.ndarray:
+        mu = np.zeros(self.d, dtype=np.float32)
+        _n.check(_n.lib.ise_index_get_shift(self._h, mu.ctypes.data))
+        return mu
+
+    def set_shift(self, mu) -> None:
+        mu = np.ascontiguousarray(mu, dtype=np.float32)
+        assert mu.shape == (self.d,)
+        _n.check(_n.lib.ise_index_set_shift(self._h, mu.ctypes.data))
+
     # -- build side
     def add(self, x) -> None:
         """Append rows (copied; the caller may mutate or free ``x`` afterwards)."""

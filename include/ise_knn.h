@@ -75,6 +75,14 @@ int ise_index_info(const ise_index_t* h, int* d, int* metric, int64_t* ntotal, i
 int ise_index_add_host(ise_index_t* h, const float* x, int64_t n);
 int ise_index_add_device(ise_index_t* h, const float* x_dev, int64_t n, void* stream);
 
+/* Float32 L2 indexes evaluate distances around a fixed shift vector mu (distances are
+ * translation invariant; see csrc/ise_knn.hip, SHIFT).  By default mu is the mean of
+ * the first rows added.  Shards of one logical index must share it: read it from the
+ * shard that holds the first rows and set it on the others BEFORE their first add.
+ * mu: d float32 on the host.  No-ops for inner-product and bf16 indexes. */
+int ise_index_set_shift(ise_index_t* h, const float* mu_host);
+int ise_index_get_shift(ise_index_t* h, float* mu_host);
+
 /* copy rows [i0, i0+n) back to host as n x d float32 (used by write_index,
  * backend/indexer.py:59). */
 int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n, float* out);

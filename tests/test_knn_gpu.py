@@ -262,6 +262,7 @@ def test_shard_keys_merge_equals_unsharded(faiss):
         for r in range(G):
             lo, hi = 12345 * r // G, 12345 * (r + 1) // G
             sh = make_index(faiss, metric, 96)
+            sh.set_shift(whole.get_shift())  # shards share the unsharded index's shift vector
             sh.add(xb[lo:hi])
             keys.append(sh.search_keys_torch(tq, 10, id_base=lo))
         D1, I1 = faiss.merge_keys_torch(torch.stack(keys), metric)
@@ -306,6 +307,7 @@ def test_full_size_properties(faiss):
     # two shards + merge
     half = n // 2
     a, b = faiss.IndexFlatL2(d), faiss.IndexFlatL2(d)
+    b.set_shift(index.get_shift())  # a fixes the same shift itself: it holds the first rows
     a.add_torch(xb[:half])
     b.add_torch(xb[half:])
     keys = torch.stack([a.search_keys_torch(xq, k, 0), b.search_keys_torch(xq, k, half)])
@@ -368,3 +370,27 @@ def test_assignment_kernel_matches_oracle(faiss, metric, n, K, d):
     dup.add(np.concatenate([cent[:5], cent[:5]]))
     Dd, Id = dup.assign_torch(torch.from_numpy(X[:300]).cuda())
     assert (Id.cpu().numpy() < 5).all()
+
+
+def test_l2_on_offset_data_like_cnn_embeddings(faiss):
+    """Rows with a large common component and a small spread (post-ReLU CNN features):
+    the expanded L2 form loses the neighbours to cancellation unless distances are taken
+    around a shift vector.  Faiss's small-batch path (direct differences) is exact here."""
+    rng = np.random.default_rng(77)
+    n, d = 20000, 512
+    xb = (40.0 + 0.05 * rng.standard_normal((n, d))).astype(np.float32)
+    xq = (xb[rng.integers(0, n, 16)] + 0.01 * rng.standard_normal((16, d))).astype(np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    assert np.abs(index.get_shift() - 40.0).max() < 0.01
+    D, I = index.search(xq, 10)
+    D_ref, I_ref = ko.knn_exact(xb, xq, 10, L2)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2, gap=ko.kth_gap(xb, xq, 10, L2))
+    assert np.array_equal(index.reconstruct_n(0, 100), xb[:100])  # rows are stored unshifted
+    # k = 1 assignment kernel on the same kind of data
+    X = (40.0 + 0.05 * rng.standard_normal((4096, d))).astype(np.float32)
+    small = faiss.IndexFlatL2(d)
+    small.add(xb[:300])
+    Da, Ia = small.search(X, 1)
+    Dr, Ir = ko.knn_exact(xb[:300], X, 1, L2)
+    assert_knn_matches(Da, Ia, Dr, Ir, xb[:300], X, L2, gap=ko.kth_gap(xb[:300], X, 1, L2))
