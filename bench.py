@@ -228,7 +228,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, d, nq, k, world),
                          "kernel": "scan_kernel", "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
-                         "algorithmic_bytes": alg_bytes},
+                         "algorithmic_bytes": alg_bytes,
+                         "kernel_ms_source": "50 back-to-back launches on one stream, HIP events around the kernel "
+                                             "(ise_index_search_timed_device); rocprofv3 agreement: "
+                                             "profiles/r01/bench_nq16_streams1_kernel_stats.csv"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(xb_host, xq_host, k)
