@@ -394,3 +394,26 @@ def test_l2_on_offset_data_like_cnn_embeddings(faiss):
     Da, Ia = small.search(X, 1)
     Dr, Ir = ko.knn_exact(xb[:300], X, 1, L2)
     assert_knn_matches(Da, Ia, Dr, Ir, xb[:300], X, L2, gap=ko.kth_gap(xb[:300], X, 1, L2))
+
+
+def test_shape_sweep_against_oracle(faiss):
+    """Many small (n, d, nq, k) combinations: odd d (scalar query staging), every query-tile
+    count (T = 1, 2, 3 and ragged last tiles), k across the single-pass limit, both metrics."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    for d in (1, 3, 17, 33, 63, 65, 130, 257, 600, 1024):
+        for nq in (1, 15, 17, 31, 33, 47, 49, 100):
+            cases.append((int(rng.integers(20, 3000)), d, nq, int(rng.integers(1, 40))))
+    rng.shuffle(cases)
+    for n, d, nq, k in cases[:48]:
+        metric = L2 if (n + d + nq) % 2 else IP
+        xb = rng.random((n, d), dtype=np.float32)
+        xq = rng.random((nq, d), dtype=np.float32)
+        index = make_index(faiss, metric, d)
+        index.add(xb)
+        D, I = index.search(xq, k)
+        D_ref, I_ref = ko.knn_exact(xb, xq, k, metric)
+        try:
+            assert_knn_matches(D, I, D_ref, I_ref, xb, xq, metric, gap=ko.kth_gap(xb, xq, k, metric))
+        except AssertionError as e:
+            raise AssertionError(f"n={n} d={d} nq={nq} k={k} metric={metric}: {e}")
