@@ -44,6 +44,8 @@ class Config:
     # images per forward pass of the batched extractor (new capability; the
     # reference runs batch 1, backend/descriptors.py:185-187)
     DNN_BATCH_SIZE = 64
+    # threads decoding images ahead of the GPU batches (new; the reference decodes inline)
+    DECODE_WORKERS = 8
 
     BOVW_CORNER_DESCRIPTIONS_PATH = MODELS_BASE_PATH / "bovw_corner_descriptions.joblib"
     BOVW_KMEANS_INDEX_PATH = MODELS_BASE_PATH / "bovw_kmeans_index.faiss"

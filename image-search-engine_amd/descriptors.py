@@ -185,17 +185,30 @@ class Describer:
                     print(f"ERROR: Problem describing image '{img_path}'\n '{e}'")
         pending.clear()
 
+    def _safe_read(self, img_path):
+        try:
+            return img_path, self.read_image(img_path), None
+        except Exception as e:
+            return img_path, None, e
+
     def describe(self, images_paths, multiprocess=False) -> dict[str, list]:
+        """Decode runs ``decode_workers`` images ahead on a thread pool (PIL releases the GIL
+        while decoding) so the GPU batches are not starved by JPEG decode (SURVEY.md 8f-4);
+        order and skip-on-error behaviour are those of the reference's sequential loop."""
+        from concurrent.futures import ThreadPoolExecutor
+
         descriptions: dict[str, list] = defaultdict(list)
         pending = []
-        for img_path in np.asarray(images_paths).ravel().tolist():
-            try:
-                pending.append((img_path, self.read_image(img_path)))
-            except Exception as e:
-                print(f"ERROR: Problem describing image '{img_path}'\n '{e}'")
-                continue
-            if len(pending) >= self.batch_size:
-                self._flush(pending, descriptions)
+        paths = np.asarray(images_paths).ravel().tolist()
+        workers = max(1, int(getattr(config, "DECODE_WORKERS", 8)))
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for img_path, image, err in pool.map(self._safe_read, paths):  # map keeps input order
+                if err is not None:
+                    print(f"ERROR: Problem describing image '{img_path}'\n '{err}'")
+                    continue
+                pending.append((img_path, image))
+                if len(pending) >= self.batch_size:
+                    self._flush(pending, descriptions)
         self._flush(pending, descriptions)
         return descriptions
 

@@ -318,31 +318,83 @@ class IndexIVFPQ:  # backend/utils.py:323 ("cell-probe"): approximate, out of sc
 
 
 class Kmeans:
-    """Holder for the nearest-centroid assignment the reference does through
-    ``faiss.Kmeans(...).index.search(X, 1)`` (backend/kmeans_faiss.py:29-50).
-    ``spherical=True`` there makes ``.index`` an inner-product index over
-    unit-norm centroids [upstream-faiss].  Only assignment is on the scoped
-    path: ``train`` accepts ``init_centroids`` (the "loaded from a file" case,
-    backend/kmeans_faiss.py:40-41) and builds ``.index`` from them; Lloyd
-    iterations are a "next" row."""
+    """``faiss.Kmeans`` as the reference drives it (backend/kmeans_faiss.py:29-44):
+    ``Kmeans(d=, k=, niter=25, nredo=3, seed=42, spherical=True)``, ``.train(x, init_centroids=)``,
+    then ``.index`` (the assignment index: inner product over unit centroids when spherical,
+    L2 otherwise [upstream-faiss]), ``.centroids`` and ``.obj``.
+
+    Assignment (``.index.search(X, 1)``) is the scoped hot path.  ``train`` is a
+    "next" row and is provided as plain Lloyd iterations on the GPU: the assignment
+    step is the MFMA assignment kernel, the centroid update a device scatter-add.  Faiss seeds its
+    initial centroids from its own RNG, so trained centroids are not comparable run-for-run with
+    Faiss's (parity unpinned).  ``init_centroids`` starts the iterations from a given codebook, as in
+    Faiss; the reference reloads a saved model without training, by handing the index to
+    ``FaissKMeans(index=...)`` (backend/bag_of_visual_words.py:207-216)."""
 
     def __init__(self, d, k, niter=25, nredo=1, seed=1234, spherical=False, verbose=False, **_):
         self.d, self.k = int(d), int(k)
-        self.niter, self.nredo, self.seed = niter, nredo, seed
-        self.spherical, self.verbose = spherical, verbose
+        self.niter, self.nredo, self.seed = int(niter), int(nredo), int(seed)
+        self.spherical, self.verbose = bool(spherical), bool(verbose)
         self.centroids = None
         self.index = None
         self.obj = np.zeros(0, dtype=np.float32)
 
-    def train(self, x, init_centroids=None):
-        if init_centroids is None:
-            raise NotImplementedError("k-means training is not on the scoped hot path; pass init_centroids")
-        c = _as_rows(init_centroids, self.d).copy()
-        assert c.shape[0] == self.k
+    def _make_index(self, c: np.ndarray):
+        index = IndexFlatIP(self.d) if self.spherical else IndexFlatL2(self.d)
+        index.add(c)
+        return index
+
+    def _lloyd(self, x_dev, c0: np.ndarray, niter: int):
+        import torch
+
+        c = torch.from_numpy(c0).to(x_dev.device)
+        obj = []
+        n = x_dev.shape[0]
+        for _ in range(niter):
+            if self.spherical:
+                normalize_L2(c)
+            index = IndexFlat(self.d, METRIC_INNER_PRODUCT if self.spherical else METRIC_L2,
+                              x_dev.device.index)
+            index.add_torch(c)
+            D, I = index.assign_torch(x_dev) if index._assign_applies(n, 1) else index.search_torch(x_dev, 1)
+            lab = I.view(-1).clamp_(min=0)
+            obj.append(float(D.sum()))
+            sums = torch.zeros_like(c).index_add_(0, lab, x_dev)
+            cnt = torch.bincount(lab, minlength=self.k).to(c.dtype)
+            empty = cnt == 0
+            c = torch.where(empty[:, None], c, sums / cnt.clamp(min=1)[:, None])
+            if bool(empty.any()):  # re-seed empty clusters from random rows
+                g = torch.Generator(device="cpu").manual_seed(self.seed + len(obj))
+                pick = torch.randint(0, n, (int(empty.sum()),), generator=g).to(x_dev.device)
+                c[empty] = x_dev[pick]
         if self.spherical:
             normalize_L2(c)
-        self.centroids = c
-        self.index = IndexFlatIP(self.d) if self.spherical else IndexFlatL2(self.d)
-        self.index.add(c)
-        self.obj = np.zeros(1, dtype=np.float32)
-        return 0.0
+        return c.cpu().numpy(), obj
+
+    def train(self, x, init_centroids=None):
+        import torch
+
+        x = _as_rows(x, self.d)
+        dev = torch.device("cuda", _default_device())
+        best = None
+        for redo in range(1 if init_centroids is not None else max(1, self.nredo)):
+            if init_centroids is not None:
+                c0 = _as_rows(init_centroids, self.d).copy()
+                assert c0.shape[0] == self.k
+            else:
+                rs = np.random.RandomState(self.seed + redo)
+                c0 = x[rs.choice(x.shape[0], self.k, replace=x.shape[0] < self.k)].copy()
+            if self.niter > 0 and x.shape[0] > 0:
+                c, obj = self._lloyd(torch.from_numpy(x).to(dev), c0, self.niter)
+            else:
+                c, obj = c0, [0.0]
+                if self.spherical:
+                    normalize_L2(c)
+            # spherical k-means maximises the summed inner product, plain k-means minimises distance
+            score = obj[-1] if self.spherical else -obj[-1]
+            if best is None or score > best[0]:
+                best = (score, c, obj)
+        _, self.centroids, obj = best
+        self.obj = np.asarray(obj, dtype=np.float32)
+        self.index = self._make_index(self.centroids)
+        return float(self.obj[-1])

@@ -1,8 +1,8 @@
 """``FaissKMeans`` with the reference's surface (backend/kmeans_faiss.py:5-50).
 ``transform`` (nearest-centroid assignment, ``self.index.search(X, 1)``) is on the
-scoped hot path and runs on the GPU; ``fit`` only accepts
-``init_centroids`` (the reference's "loaded from a file" case) -- Lloyd training is a
-"next" row."""
+scoped hot path and runs on the GPU as one MFMA-bound kernel; ``fit``
+drives ``faiss_compat.Kmeans`` (GPU Lloyd iterations, a "next" row).  A saved
+codebook is reloaded the reference's way: ``FaissKMeans(n_clusters, index=read_index(path))``."""
 from __future__ import annotations
 
 import numpy as np

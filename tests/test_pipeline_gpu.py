@@ -84,12 +84,53 @@ def test_faiss_kmeans_transform_is_nearest_centroid(golden_dir):
 
     from image_search_engine_amd.kmeans_faiss import FaissKMeans
 
+    import image_search_engine_amd.faiss_compat as faiss
+
     z = np.load(os.path.join(golden_dir, "assign_ip_n512_c256_d128.npz"))
-    km = FaissKMeans(n_clusters=256, init_centroids=z["xb"])
-    km.fit(z["xq"])
-    assert km.index.ntotal == 256 and km.cluster_centers_.shape == (256, 128)
+    # the reference reloads a saved codebook as FaissKMeans(n_clusters, index=read_index(...))
+    # (backend/bag_of_visual_words.py:207-216); spherical k-means -> inner-product index
+    index = faiss.IndexFlatIP(128)
+    index.add(z["xb"])
+    km = FaissKMeans(n_clusters=256, index=index)
+    assert km.index.ntotal == 256
     I = km.transform(z["xq"])
     assert I.dtype == np.int64 and I.shape == (512, 1)
     assert np.array_equal(I, z["I"])
     hist, _ = np.histogram(I, bins=256)  # BoVW histogram as at backend/bag_of_visual_words.py:103
     assert hist.sum() == 512
+
+
+def test_kmeans_train_lloyd_on_gpu():
+    """spherical k-means as backend/kmeans_faiss.py:29-44 configures it.  Planted
+    well-separated directions must be recovered; the objective must not decrease."""
+    import image_search_engine_amd.faiss_compat as faiss
+    from image_search_engine_amd.kmeans_faiss import FaissKMeans
+
+    rng = np.random.default_rng(0)
+    K, d, per = 12, 64, 300
+    dirs = rng.standard_normal((K, d)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    X = np.concatenate([dirs[i] * rng.uniform(50, 100, (per, 1)) + 0.5 * rng.standard_normal((per, d))
+                        for i in range(K)]).astype(np.float32)
+    km = FaissKMeans(n_clusters=K, n_init=3, max_iter=25)
+    km.fit(X)
+    assert km.cluster_centers_.shape == (K, d)
+    np.testing.assert_allclose(np.linalg.norm(km.cluster_centers_, axis=1), 1.0, rtol=1e-5)  # spherical
+    labels = km.transform(X).ravel()
+    truth = np.repeat(np.arange(K), per)
+    # Lloyd from random rows may stop in a local optimum (as Faiss's does): ask for high purity,
+    # and for exact recovery when started from the planted directions
+    purity = sum(np.bincount(truth[labels == c]).max() for c in set(labels.tolist())) / len(labels)
+    assert purity > 0.75, purity
+    seeded = FaissKMeans(n_clusters=K, max_iter=5, init_centroids=dirs)
+    seeded.fit(X)
+    ls = seeded.transform(X).ravel()
+    assert np.array_equal(ls, truth)
+    obj = km.kmeans.obj
+    assert (np.diff(obj) >= -1e-3 * np.abs(obj[:-1])).all()  # summed inner product never drops
+    assert abs(km.inertia_ - obj[-1]) < 1e-6 * abs(obj[-1]) + 1e-6
+    # plain (non-spherical) k-means through the same class
+    plain = faiss.Kmeans(d=d, k=K, niter=10, nredo=1, seed=1, spherical=False)
+    plain.train(X)
+    _, I = plain.index.search(X, 1)
+    assert len(set(I.ravel().tolist())) == K
