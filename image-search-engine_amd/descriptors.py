@@ -17,6 +17,7 @@ differs from cv2's 11-bit fixed-point uint8 resize by <= 1 LSB before normalisat
 """
 from __future__ import annotations
 
+import collections
 from collections import defaultdict
 from typing import Protocol
 
@@ -201,8 +202,19 @@ class Describer:
         pending = []
         paths = np.asarray(images_paths).ravel().tolist()
         workers = max(1, int(getattr(config, "DECODE_WORKERS", 8)))
+        window = max(workers * 4, self.batch_size)  # decoded images held ahead of the GPU: bounded
         with ThreadPoolExecutor(max_workers=workers) as pool:
-            for img_path, image, err in pool.map(self._safe_read, paths):  # map keeps input order
+            inflight = collections.deque()
+            it = iter(paths)
+            while True:
+                while len(inflight) < window:
+                    nxt = next(it, None)
+                    if nxt is None:
+                        break
+                    inflight.append(pool.submit(self._safe_read, nxt))
+                if not inflight:
+                    break
+                img_path, image, err = inflight.popleft().result()  # input order is kept
                 if err is not None:
                     print(f"ERROR: Problem describing image '{img_path}'\n '{err}'")
                     continue
