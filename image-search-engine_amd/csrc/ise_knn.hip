@@ -48,7 +48,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 #define KEY_PAD (~0ull)
-#define QT 16 /* queries per scan tile (one MFMA column block) */
 
 // ---------------------------------------------------------------- device utils
 __device__ __forceinline__ uint32_t ord_f32(float f) {
@@ -107,7 +106,7 @@ struct ScanParams {
     const u64* floor_keys;  // optional [nq]: only keys > floor enter (k > 64 passes)
     u64* part;           // [nqt][nb][16 T][k]
     long long n;         // rows in the index
-    int d, dp, qs_stride;  // qs_stride: LDS query row stride in floats (f32) / bf16 pairs... see SS
+    int d, dp, qs_stride;  // qs_stride: LDS query row stride in 4-byte units (floats, or bf16 pairs)
     int row_slots;         // 16-byte slots per index row = dp * elem_size / 16; one k-step = 4 slots
     int nq, k, kb, metric;  // kb: block-list slots per query (16 or 32, >= k)
     uint32_t id_base;
@@ -1037,19 +1036,31 @@ __global__ __launch_bounds__(256) void norms_kernel(const float* __restrict__ x,
     if (lane == 0) out[r] = s;
 }
 
-// mean of the first `rows` rows per column (d columns of a padded row), summed in row
-// order by one thread per column: deterministic, so every index built from the same
-// leading rows gets the same shift vector
-__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ x, long long rows, int d, int dp,
+// mean of the first `rows` rows per column (d columns of a padded row).  Two levels, both in a
+// fixed order (COLMEAN_GROUPS row groups summed in row order, then the groups in group order):
+// deterministic, so every index built from the same leading rows gets the same shift vector.
+#define COLMEAN_GROUPS 64
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, long long rows, int d, int dp,
+                                                      float* __restrict__ partial /* [GROUPS][dp] */) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gidx = blockIdx.y;
+    if (j >= dp) return;
+    const long long per = (rows + COLMEAN_GROUPS - 1) / COLMEAN_GROUPS;
+    const long long r0 = gidx * per, r1 = min(rows, r0 + per);
+    float s = 0.f;
+    if (j < d)
+        for (long long r = r0; r < r1; r++) {
+            const float v = x[(size_t)r * dp + j];
+            if (fabsf(v) <= FLT_MAX) s += v;  // NaN / inf entries must not poison every distance
+        }
+    partial[(size_t)gidx * dp + j] = s;
+}
+__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ partial, long long rows, int d, int dp,
                                                        float* __restrict__ mu) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= dp) return;
     float s = 0.f;
-    if (j < d)
-        for (long long r = 0; r < rows; r++) {
-            const float v = x[(size_t)r * dp + j];
-            if (fabsf(v) <= FLT_MAX) s += v;  // NaN / inf entries must not poison every distance
-        }
+    for (int gi = 0; gi < COLMEAN_GROUPS; gi++) s += partial[(size_t)gi * dp + j];
     const float m = s / (float)rows;
     mu[j] = (j < d && fabsf(m) <= FLT_MAX) ? m : 0.f;
 }
@@ -1117,6 +1128,32 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ x, l
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
     float* xr = x + (size_t)r * d;
+    constexpr int VMAX = 8;  // up to 8 float4 per lane: rows of <= 2048 floats stay in registers
+    const bool vec = (d & 3) == 0 && d <= 64 * 4 * VMAX && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec) {  // one read, one write
+        f32x4 v[VMAX];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VMAX; i++) {
+            const int j = (lane + 64 * i) * 4;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (j < d) v[i] = *reinterpret_cast<const f32x4*>(xr + j);
+            s = fmaf(v[i][0], v[i][0], s);
+            s = fmaf(v[i][1], v[i][1], s);
+            s = fmaf(v[i][2], v[i][2], s);
+            s = fmaf(v[i][3], v[i][3], s);
+        }
+        s = wave_sum_f32(s);
+        if (s > 0.f) {
+            const float inv = (float)(1.0 / (double)sqrtf(s));
+#pragma unroll
+            for (int i = 0; i < VMAX; i++) {
+                const int j = (lane + 64 * i) * 4;
+                if (j < d) *reinterpret_cast<f32x4*>(xr + j) = v[i] * inv;
+            }
+        }
+        return;
+    }
     float s = 0.f;
     for (int j = lane; j < d; j += 64) {
         const float v = xr[j];
@@ -1379,9 +1416,15 @@ static bool uses_shift(const ise_index* h) { return h->storage == ISE_STORE_F32 
 static int fix_shift_from_first_rows(ise_index* h, long long n_new, hipStream_t st) {
     if (!uses_shift(h) || h->shift_set) return ISE_OK;
     const long long rows = std::min<long long>(n_new, SHIFT_SAMPLE_ROWS);
-    hipLaunchKernelGGL(col_mean_kernel, dim3((h->dp + 255) / 256), dim3(256), 0, st, (const float*)h->xb, rows, h->d,
-                       h->dp, h->mu);
-    HIP_TRY(hipGetLastError());
+    float* partial = nullptr;
+    HIP_TRY(hipMalloc(&partial, (size_t)COLMEAN_GROUPS * h->dp * sizeof(float)));
+    hipLaunchKernelGGL(col_sum_kernel, dim3((h->dp + 255) / 256, COLMEAN_GROUPS), dim3(256), 0, st,
+                       (const float*)h->xb, rows, h->d, h->dp, partial);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((h->dp + 255) / 256), dim3(256), 0, st, partial, rows, h->d, h->dp, h->mu);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // partial is freed below
+    (void)hipFree(partial);
+    if (e != hipSuccess) return fail(ISE_E_HIP, std::string("shift vector: ") + hipGetErrorString(e));
     h->shift_set = true;
     return ISE_OK;
 }
