@@ -128,7 +128,7 @@ def main():
     # Independent batches are issued round-robin onto a few HIP streams so that the
     # latency phases of one batch (query staging, threshold boot, final selection, merge,
     # and for N > 1 the all-gather) overlap the streaming phase of the next one.
-    n_streams = max(1, int(os.environ.get("ISE_BENCH_STREAMS", "2")))
+    n_streams = max(1, int(os.environ.get("ISE_BENCH_STREAMS", "4")))
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
 
     if world > 1:
