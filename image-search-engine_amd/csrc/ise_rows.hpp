@@ -1,0 +1,156 @@
+// ise_rows.hpp -- wave-per-row helper kernels: norms, padding / conversion, normalize_L2, shift vector.
+#pragma once
+#include "ise_common.hpp"
+
+// ---------------------------------------------------------------- row helpers
+// |y|^2 per row, wave per row, fixed summation order (lanes stride float4, then
+// an xor butterfly): deterministic for a given dp.
+__global__ __launch_bounds__(256) void norms_kernel(const float* __restrict__ x, long long row0,
+                                                    long long n, int dp, const float* __restrict__ mu,
+                                                    float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = row0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= row0 + n) return;
+    const float* xr = x + (size_t)r * dp;
+    float s = 0.f;
+    for (int j = lane * 4; j < dp; j += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + j);
+        if (mu) v = v - *reinterpret_cast<const f32x4*>(mu + j);  // |y - mu|^2 (padding columns: 0 - 0)
+        s = fmaf(v[0], v[0], s);
+        s = fmaf(v[1], v[1], s);
+        s = fmaf(v[2], v[2], s);
+        s = fmaf(v[3], v[3], s);
+    }
+    s = wave_sum_f32(s);
+    if (lane == 0) out[r] = s;
+}
+
+// mean of the first `rows` rows per column (d columns of a padded row).  Two levels, both in a
+// fixed order (COLMEAN_GROUPS row groups summed in row order, then the groups in group order):
+// deterministic, so every index built from the same leading rows gets the same shift vector.
+#define COLMEAN_GROUPS 64
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, long long rows, int d, int dp,
+                                                      float* __restrict__ partial /* [GROUPS][dp] */) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gidx = blockIdx.y;
+    if (j >= dp) return;
+    const long long per = (rows + COLMEAN_GROUPS - 1) / COLMEAN_GROUPS;
+    const long long r0 = gidx * per, r1 = min(rows, r0 + per);
+    float s = 0.f;
+    if (j < d)
+        for (long long r = r0; r < r1; r++) {
+            const float v = x[(size_t)r * dp + j];
+            if (fabsf(v) <= FLT_MAX) s += v;  // NaN / inf entries must not poison every distance
+        }
+    partial[(size_t)gidx * dp + j] = s;
+}
+__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ partial, long long rows, int d, int dp,
+                                                       float* __restrict__ mu) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= dp) return;
+    float s = 0.f;
+    for (int gi = 0; gi < COLMEAN_GROUPS; gi++) s += partial[(size_t)gi * dp + j];
+    const float m = s / (float)rows;
+    mu[j] = (j < d && fabsf(m) <= FLT_MAX) ? m : 0.f;
+}
+
+// |y|^2 of bf16 rows (the values the bf16 scan multiplies), fp32 accumulation
+__global__ __launch_bounds__(256) void norms_bf16_kernel(const __bf16* __restrict__ x, long long row0, long long n,
+                                                         int dp, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = row0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= row0 + n) return;
+    const __bf16* xr = x + (size_t)r * dp;
+    float s = 0.f;
+    for (int j = lane * 8; j < dp; j += 512) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + j);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float f = (float)v[e];
+            s = fmaf(f, f, s);
+        }
+    }
+    s = wave_sum_f32(s);
+    if (lane == 0) out[r] = s;
+}
+
+// float32 rows (unpadded) -> padded bf16 index rows (round to nearest even)
+__global__ __launch_bounds__(256) void pad_rows_bf16_kernel(const float* __restrict__ src, long long n, int d,
+                                                            __bf16* __restrict__ dst, int dp) {
+    const long long total = n * dp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / dp;
+        const int j = (int)(i - r * dp);
+        dst[i] = (__bf16)(j < d ? src[(size_t)r * d + j] : 0.f);
+    }
+}
+
+// padded bf16 rows -> float32 rows of d (reconstruct / write_index)
+__global__ __launch_bounds__(256) void unpack_rows_bf16_kernel(const __bf16* __restrict__ src, long long n, int d,
+                                                               int dp, float* __restrict__ dst) {
+    const long long total = n * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / d;
+        const int j = (int)(i - r * d);
+        dst[i] = (float)src[(size_t)r * dp + j];
+    }
+}
+
+// copy n rows of d floats (unpadded, src) into the padded index layout
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, long long n, int d,
+                                                       float* __restrict__ dst, int dp) {
+    const long long total = n * dp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / dp;
+        const int j = (int)(i - r * dp);
+        dst[i] = j < d ? src[(size_t)r * d + j] : 0.f;
+    }
+}
+
+// faiss.normalize_L2 [upstream-faiss fvec_renorm_L2]: nr = |x|^2 (float32);
+// if nr > 0: x *= (float)(1.0 / sqrtf(nr)).  Wave per row.
+__global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ x, long long n, int d) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float* xr = x + (size_t)r * d;
+    constexpr int VMAX = 8;  // up to 8 float4 per lane: rows of <= 2048 floats stay in registers
+    const bool vec = (d & 3) == 0 && d <= 64 * 4 * VMAX && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec) {  // one read, one write
+        f32x4 v[VMAX];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VMAX; i++) {
+            const int j = (lane + 64 * i) * 4;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (j < d) v[i] = *reinterpret_cast<const f32x4*>(xr + j);
+            s = fmaf(v[i][0], v[i][0], s);
+            s = fmaf(v[i][1], v[i][1], s);
+            s = fmaf(v[i][2], v[i][2], s);
+            s = fmaf(v[i][3], v[i][3], s);
+        }
+        s = wave_sum_f32(s);
+        if (s > 0.f) {
+            const float inv = (float)(1.0 / (double)sqrtf(s));
+#pragma unroll
+            for (int i = 0; i < VMAX; i++) {
+                const int j = (lane + 64 * i) * 4;
+                if (j < d) *reinterpret_cast<f32x4*>(xr + j) = v[i] * inv;
+            }
+        }
+        return;
+    }
+    float s = 0.f;
+    for (int j = lane; j < d; j += 64) {
+        const float v = xr[j];
+        s = fmaf(v, v, s);
+    }
+    s = wave_sum_f32(s);
+    if (s > 0.f) {
+        const float inv = (float)(1.0 / (double)sqrtf(s));
+        for (int j = lane; j < d; j += 64) xr[j] *= inv;
+    }
+}
