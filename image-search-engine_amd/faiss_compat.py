@@ -187,6 +187,18 @@ class IndexFlat:
                                                     I.data_ptr(), st))
         return D, I
 
+    # -- allocation-free forms for latency-critical loops (bench.py, sharded search): the caller owns
+    # every buffer and names the stream; nothing is checked beyond what the C ABI checks
+    def search_into(self, xq, k: int, D, I, stream: int) -> None:
+        with self._lock:
+            _n.check(_n.lib.ise_index_search_device(self._h, xq.data_ptr(), xq.shape[0], int(k), D.data_ptr(),
+                                                    I.data_ptr(), stream))
+
+    def search_keys_into(self, xq, k: int, id_base: int, keys, stream: int) -> None:
+        with self._lock:
+            _n.check(_n.lib.ise_index_search_keys_device(self._h, xq.data_ptr(), xq.shape[0], int(k), int(id_base),
+                                                         keys.data_ptr(), stream))
+
     def search_keys_torch(self, xq, k: int, id_base: int = 0):
         """Shard-local search for the multi-GPU path: packed uint64 candidates
         (as an int64 tensor (nq,k)), see include/ise_knn.h."""
@@ -244,6 +256,13 @@ def merge_keys_torch(keys, metric: int):
     _n.check(_n.lib.ise_merge_keys_device(keys.data_ptr(), n_lists, nq, k, int(metric), D.data_ptr(), I.data_ptr(),
                                           keys.device.index, st))
     return D, I
+
+
+def merge_keys_into(keys, metric: int, D, I, stream: int) -> None:
+    """Allocation-free form of ``merge_keys_torch``: keys int64 CUDA (n_lists, nq, k) contiguous."""
+    n_lists, nq, k = keys.shape
+    _n.check(_n.lib.ise_merge_keys_device(keys.data_ptr(), n_lists, nq, k, int(metric), D.data_ptr(), I.data_ptr(),
+                                          keys.device.index, stream))
 
 
 def normalize_L2(x) -> None:

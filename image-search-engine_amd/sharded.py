@@ -50,6 +50,13 @@ class HipShardBackend:
     def merge(self, keys_all: torch.Tensor):
         return self._fc.merge_keys_torch(keys_all, self.metric)
 
+    # allocation-free forms (caller-owned buffers, work enqueued on the current stream)
+    def local_search_keys_into(self, xq: torch.Tensor, k: int, id_base: int, keys: torch.Tensor) -> None:
+        self.index.search_keys_into(xq, k, id_base, keys, torch.cuda.current_stream(self.device).cuda_stream)
+
+    def merge_into(self, keys_all: torch.Tensor, D: torch.Tensor, I: torch.Tensor) -> None:
+        self._fc.merge_keys_into(keys_all, self.metric, D, I, torch.cuda.current_stream(self.device).cuda_stream)
+
 
 class ShardedIndexFlat:
     """IndexFlat whose rows are split over the ranks of a process group."""
@@ -105,18 +112,35 @@ class ShardedIndexFlat:
             raise RuntimeError("a sharded index holds fewer than 2^32 rows")
 
     # -- query side
-    def search_begin(self, xq: torch.Tensor, k: int):
+    def make_buffers(self, nq: int, k: int):
+        """Caller-owned buffers for the allocation-free ``search_begin/search_end`` form: one set per
+        batch in flight."""
+        dev = getattr(self.backend, "device", torch.device("cpu"))
+        return {"keys": torch.empty((nq, k), dtype=torch.int64, device=dev),
+                "gathered": torch.empty((self.world, nq, k), dtype=torch.int64, device=dev),
+                "D": torch.empty((nq, k), dtype=torch.float32, device=dev),
+                "I": torch.empty((nq, k), dtype=torch.int64, device=dev)}
+
+    def search_begin(self, xq: torch.Tensor, k: int, bufs=None):
         """Enqueue the shard-local scan and start the all-gather; returns a ticket for
         ``search_end``.  Issuing the next ``search_begin`` before ``search_end`` overlaps
-        the collective of batch i with the scan of batch i+1."""
-        keys = self.backend.local_search_keys(xq, k, self.id_base)
-        gathered = torch.empty((self.world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
+        the collective of batch i with the scan of batch i+1.  With ``bufs`` (``make_buffers``)
+        nothing is allocated on the way."""
+        if bufs is not None and hasattr(self.backend, "local_search_keys_into"):
+            keys, gathered = bufs["keys"], bufs["gathered"]
+            self.backend.local_search_keys_into(xq, k, self.id_base, keys)
+        else:
+            keys = self.backend.local_search_keys(xq, k, self.id_base)
+            gathered = torch.empty((self.world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
         work = dist.all_gather_into_tensor(gathered.view(-1), keys.view(-1), group=self.group, async_op=True)
-        return work, gathered
+        return work, gathered, bufs
 
     def search_end(self, ticket):
-        work, gathered = ticket
+        work, gathered, bufs = ticket
         work.wait()
+        if bufs is not None and hasattr(self.backend, "merge_into"):
+            self.backend.merge_into(gathered, bufs["D"], bufs["I"])
+            return bufs["D"], bufs["I"]
         return self.backend.merge(gathered)
 
     def search(self, xq: torch.Tensor, k: int):
