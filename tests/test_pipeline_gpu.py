@@ -134,3 +134,52 @@ def test_kmeans_train_lloyd_on_gpu():
     plain.train(X)
     _, I = plain.index.search(X, 1)
     assert len(set(I.ravel().tolist())) == K
+
+
+def test_query_index_both_branches_match_reference_formulas():
+    """backend/siamese/test_index.py:49-71: faiss branch = normalise + IP search; dict branch =
+    normalise + per-row np.linalg.norm + argsort (non-squared L2, returns (indices, distances))."""
+    import image_search_engine_amd.faiss_compat as faiss
+    from image_search_engine_amd.query_index import query_index
+
+    rng = np.random.default_rng(12)
+    rows = rng.standard_normal((400, 128))
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)  # float64 unit rows (create_index.py:62-85)
+    emb = rng.standard_normal((1, 128))
+    # reference arithmetic, restated inline
+    e = emb / np.linalg.norm(emb)
+    dist = np.array([np.linalg.norm(rows[i, :] - e) for i in range(len(rows))])
+    order = dist.argsort()[:9]
+    ind, dis = query_index(emb.copy(), rows, "dict", 9)
+    assert np.array_equal(np.asarray(ind), order)
+    np.testing.assert_allclose(dis, dist[order], rtol=1e-5)
+    # faiss branch over an inner-product index of the same rows: same neighbours, cos = 1 - d^2/2
+    index = faiss.IndexFlatIP(128)
+    index.add(rows.astype(np.float32))
+    e32 = emb.astype(np.float32).copy()
+    ind2, dis2 = query_index(e32, index, "faiss", 9)
+    assert ind2 == order.tolist()
+    np.testing.assert_allclose(np.linalg.norm(e32), 1.0, rtol=1e-6)  # normalised in place
+    np.testing.assert_allclose(dis2, 1.0 - dist[order] ** 2 / 2.0, atol=1e-5)
+
+
+def test_bench_contract_small():
+    """bench.py keeps its JSON contract (one line, required keys, roofline + cpu_baseline)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--n", "60000", "--steps", "5", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 5 and r["dtype"] == "f32" and r["config"]["workload"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(r["cpu_baseline"])
+    assert r["ids_identical"] and r["recall_at_k"] == 1.0
