@@ -1,52 +1,64 @@
-"""Configuration constants with the reference's attribute names
-(backend/config.py:8-109).  The reference's ``DATA_FOLDER_PATH = FILL THIS PATH``
-(backend/config.py:46) is a SyntaxError; here it defaults to ``./data`` and can
-be overridden with the ISE_DATA_FOLDER environment variable."""
+"""Configuration constants under the reference's attribute names (backend/config.py:8-109), so the
+mirrored modules read ``config.X`` exactly as the reference's do.
+
+Differences, all deliberate:
+  * the reference's ``DATA_FOLDER_PATH = FILL THIS PATH`` (backend/config.py:46) is a SyntaxError;
+    here the data and model folders come from ``$ISE_DATA_FOLDER`` / ``$ISE_MODELS_FOLDER``
+    (defaults ``data`` / ``models``);
+  * ``METHOD`` defaults to DNN, the scoped hot path (the reference defaults to BOVW,
+    backend/config.py:61);
+  * ``DNN_BATCH_SIZE`` and ``DECODE_WORKERS`` are new knobs of the batched extractor;
+  * knobs of out-of-scope subsystems (BoVW grid search, cluster scoring) are not carried over.
+"""
 import logging
 import os
 from dataclasses import dataclass
 from enum import Enum
 from pathlib import Path
 
-
-class Method(Enum):
-    BOVW = 1
-    DNN = 2
-    DHASH = 3
+# same member names and values as backend/config.py:8-16
+Method = Enum("Method", ["BOVW", "DNN", "DHASH"])
+DnnModels = Enum("DnnModels", ["RESNET", "BiT"])
 
 
-class DnnModels(Enum):
-    RESNET = 1
-    BiT = 2
+def _folder(env: str, default: str) -> Path:
+    return Path(os.environ.get(env, default))
+
+
+_MODELS = _folder("ISE_MODELS_FOLDER", "models")
+
+
+def _model_file(name: str) -> Path:
+    return _MODELS / name
 
 
 @dataclass
 class Config:
-    # un-annotated class attributes, i.e. plain constants, as in the reference
+    # Un-annotated class attributes are plain constants, not dataclass fields -- as in the reference.
+
+    # ---- general
     LOGGING_LEVEL = logging.INFO
-    LOGGING_FORMAT = "%(levelname)-5s: @%(funcName)-25s | %(message)s"
-    RESIZE_SIZE = 224
-    EXTENSIONS = ("*.jpg", "*.jpeg", "*.png")
-    NUM_IMAGES_TO_RETURN = 20
-    N_JOBS = 1
-    DATA_FOLDER_PATH = Path(os.environ.get("ISE_DATA_FOLDER", "data"))
-    MODELS_BASE_PATH = Path(os.environ.get("ISE_MODELS_FOLDER", "models"))
+    LOGGING_FORMAT = "%(levelname)-5s: " + "@%(funcName)-25s | %(message)s"
+    RESIZE_SIZE = 224                       # side of the square the CNN sees
+    EXTENSIONS = tuple("*." + ext for ext in ("jpg", "jpeg", "png"))
+    NUM_IMAGES_TO_RETURN = 20               # k of the served query
+    N_JOBS = 1                              # joblib threads of describe_dataset
     THUMBNAIL_SIZE = 256
     DEVICE = "cuda"
+    DATA_FOLDER_PATH = _folder("ISE_DATA_FOLDER", "data")
+    MODELS_BASE_PATH = _MODELS
 
-    # the scoped hot path is the DNN method (the reference defaults to BOVW,
-    # backend/config.py:61)
+    # ---- which pipeline, which index
     METHOD = Method.DNN
-    INDEX_TYPE = "l2"  # cosine, l2 ("cell-probe" is out of scope)
+    INDEX_TYPE = "l2"                       # "cosine" | "l2"  ("cell-probe" is out of scope)
 
+    # ---- DNN path
     DNN_MODEL = DnnModels.RESNET
-    DNN_INDEX_PATH = MODELS_BASE_PATH / "resnet50_dnn_index.faiss"
-    # images per forward pass of the batched extractor (new capability; the
-    # reference runs batch 1, backend/descriptors.py:185-187)
-    DNN_BATCH_SIZE = 64
-    # threads decoding images ahead of the GPU batches (new; the reference decodes inline)
-    DECODE_WORKERS = 8
+    DNN_INDEX_PATH = _model_file("resnet50_dnn_index.faiss")
+    DNN_BATCH_SIZE = 64                     # images per forward pass (the reference runs batch 1)
+    DECODE_WORKERS = 8                      # threads decoding images ahead of the GPU batches
 
-    BOVW_CORNER_DESCRIPTIONS_PATH = MODELS_BASE_PATH / "bovw_corner_descriptions.joblib"
-    BOVW_KMEANS_INDEX_PATH = MODELS_BASE_PATH / "bovw_kmeans_index.faiss"
+    # ---- BoVW artefacts the hot path still consults
+    BOVW_CORNER_DESCRIPTIONS_PATH = _model_file("bovw_corner_descriptions.joblib")  # quirk 5.9-5
+    BOVW_KMEANS_INDEX_PATH = _model_file("bovw_kmeans_index.faiss")
     NUM_CLUSTERS = 200
