@@ -470,7 +470,8 @@ static void launch_scan_v(int ch, int waves, int T, dim3 grid, size_t lds, hipSt
     if (T == 1 && waves == 4) launch_scan_ch<4, 1, BF16, SHIFT>(ch, grid, lds, st, sp);
     else if (T == 1) launch_scan_ch<8, 1, BF16, SHIFT>(ch, grid, lds, st, sp);
     else if (T == 2) launch_scan_ch<8, 2, BF16, SHIFT>(ch, grid, lds, st, sp);
-    else launch_scan_ch<8, 3, BF16, SHIFT>(ch, grid, lds, st, sp);
+    else if (T == 3) launch_scan_ch<8, 3, BF16, SHIFT>(ch, grid, lds, st, sp);
+    else if constexpr (BF16) launch_scan_ch<8, 4, true, false>(ch, grid, lds, st, sp);  // 64 queries per pass: bf16 rows only
 }
 static void launch_scan(const ise_index* h, int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st,
                         const ScanParams& sp) {
@@ -497,10 +498,14 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     }
 #endif
     // relative time of one pass over the index with T query tiles (measured, 1M x 512)
-    static const double pass_cost[4] = {0.0, 1.0, 1.08, 1.25};
-    int tmax = 3;
+    // (fp32: T = 3 is MFMA-bound; bf16 rows stay HBM-bound, the growth is top-k bookkeeping)
+    static const double pass_cost_f32[5] = {0.0, 1.0, 1.2, 1.6, 0.0};
+    static const double pass_cost_bf16[5] = {0.0, 1.0, 1.17, 1.25, 1.4};
+    const bool bf16 = h->storage == ISE_STORE_BF16;
+    const double* pass_cost = bf16 ? pass_cost_bf16 : pass_cost_f32;
+    int tmax = bf16 ? 4 : 3;
 #ifdef ISE_ABLATE
-    if (const char* e = getenv("ISE_TMAX")) tmax = std::min(3, std::max(1, atoi(e)));
+    if (const char* e = getenv("ISE_TMAX")) tmax = std::min(tmax, std::max(1, atoi(e)));
 #endif
     pl->T = 0;
     double best = 0;
