@@ -533,21 +533,25 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
             for (int t = 0; t < T; t++) tau_sc[t] = unord_f32((uint32_t)(tau[t] >> 32));
             return;
         }
-        // fast path: a row can only enter if its score does not exceed the threshold's
-        // score (ties on the score are settled by the exact key compare below)
-        bool pend = false;
+        // fast path: a row can only enter if its score does not exceed the threshold's score
+        // (ties on the score are settled by the exact key compare below).  One ballot per
+        // (query tile, row slot); keys are built only for the slots some lane may fill.
 #pragma unroll
         for (int t = 0; t < T; t++) {
             tau[t] = min_u64(tau[t], tauS[t * 16 + c]);  // other waves' merges tighten it
             tau_sc[t] = unord_f32((uint32_t)(tau[t] >> 32));
         }
+        u64 hit[T][4];
+        u64 any_hit = 0;
 #pragma unroll
         for (int t = 0; t < T; t++)
-            pend = pend || sc[t][0] <= tau_sc[t] || sc[t][1] <= tau_sc[t] || sc[t][2] <= tau_sc[t] ||
-                   sc[t][3] <= tau_sc[t];
-        if (__any(pend) && !ABL(2)) {
-            u64 key[T][4];
-            make_keys(etile, sc, key);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                hit[t][j] = __ballot(sc[t][j] <= tau_sc[t]);
+                any_hit |= hit[t][j];
+            }
+        if (any_hit && !ABL(2)) {
+            const long long row0 = (long long)etile * 16 + 4 * g;
             const u64 qmask = 0x0001000100010001ull << c;  // lanes holding the same query
             const u64 lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
@@ -555,17 +559,23 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
                 u64* mybuf = cand + (size_t)(w * NQ + t * 16 + c) * CAP;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const bool v = key[t][j] < tau[t];
-                    const u64 m = __ballot(v);
-                    if (m) {
-                        const u64 mq = m & qmask;
-                        if (v) mybuf[cnt[t] + __popcll(mq & lt_mask)] = key[t][j];
-                        cnt[t] += __popcll(mq);
-                        u64 nm = __ballot(cnt[t] >= MERGE_TRIG) & 0xFFFFull;
-                        while (nm) {
-                            const int cq = __ffsll((long long)nm) - 1;
-                            nm &= nm - 1;
-                            merge_out(t, cq);
+                    if (hit[t][j]) {  // wave-uniform
+                        const float s_ = sc[t][j];
+                        bool ok = (row0 + j < p.n) && (s_ < FLT_MAX) && (t * 16 + c < nqt);
+                        const u64 kj = ((u64)ord_f32(s_) << 32) | (uint32_t)((uint32_t)(row0 + j) + p.id_base);
+                        if (use_floor) ok = ok && (kj > p.floor_keys[q0 + min(t * 16 + c, nqt - 1)]);  // multi-pass k only
+                        const bool v = ok && kj < tau[t];
+                        const u64 m = __ballot(v);
+                        if (m) {
+                            const u64 mq = m & qmask;
+                            if (v) mybuf[cnt[t] + __popcll(mq & lt_mask)] = kj;
+                            cnt[t] += __popcll(mq);
+                            u64 nm = __ballot(cnt[t] >= MERGE_TRIG) & 0xFFFFull;
+                            while (nm) {
+                                const int cq = __ffsll((long long)nm) - 1;
+                                nm &= nm - 1;
+                                merge_out(t, cq);
+                            }
                         }
                     }
                 }
