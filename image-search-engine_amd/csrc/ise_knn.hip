@@ -873,7 +873,10 @@ extern "C" int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int6
     mp.stride_qtile = (long long)k; mp.qt = 1;
     mp.n_lists = n_lists; mp.nq = (int)nq; mp.k = k; mp.metric = metric;
     mp.D = D_dev; mp.I = (long long*)I_dev; mp.keys_out = nullptr;
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, (hipStream_t)stream, mp);
+    if (n_lists <= 64)
+        hipLaunchKernelGGL(merge_small_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mp);
+    else
+        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, (hipStream_t)stream, mp);
     HIP_TRY(hipGetLastError());
     return ISE_OK;
 }

@@ -29,6 +29,9 @@ __device__ __forceinline__ void emit_result(const MergeParams& p, size_t o, u64 
     }
 }
 
+// Each list keeps its head AND the element behind it in registers: when a head wins, the next one
+// is already there and the load of the one after is issued without being waited for, so a round
+// costs a reduction and a barrier, not an L2 round trip.
 __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams p) {
     __shared__ u64 wmin[2][MERGE_THREADS / 64];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -36,13 +39,14 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
     const u64* base = p.lists + (size_t)(q / p.qt) * p.stride_qtile + (size_t)(q % p.qt) * k;
     const u64* lst[MERGE_LPT];
     int pos[MERGE_LPT];
-    u64 cur[MERGE_LPT];
+    u64 cur[MERGE_LPT], nxt[MERGE_LPT];
 #pragma unroll
     for (int e = 0; e < MERGE_LPT; e++) {
         const int l = tid + e * MERGE_THREADS;
         lst[e] = base + (size_t)(l < p.n_lists ? l : 0) * p.stride_list;
         pos[e] = 0;
         cur[e] = l < p.n_lists ? lst[e][0] : KEY_PAD;
+        nxt[e] = (l < p.n_lists && k > 1) ? lst[e][1] : KEY_PAD;
     }
     for (int r = 0; r < k; r++) {
         u64 m = cur[0];
@@ -63,8 +67,36 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
                 if (cur[e] == m) {
                     emit_result(p, o, m);
                     pos[e]++;
-                    cur[e] = pos[e] < k ? lst[e][pos[e]] : KEY_PAD;
+                    cur[e] = nxt[e];
+                    nxt[e] = pos[e] + 1 < k ? lst[e][pos[e] + 1] : KEY_PAD;
                 }
+        }
+    }
+}
+
+// Up to 64 lists (the all-gathered per-rank lists of the multi-GPU path): one wave per query,
+// one list per lane, no LDS and no barriers.
+__global__ __launch_bounds__(256) void merge_small_kernel(const MergeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.nq) return;
+    const int k = p.k;
+    const u64* lst = p.lists + (size_t)(q / p.qt) * p.stride_qtile + (size_t)(q % p.qt) * k +
+                     (size_t)(lane < p.n_lists ? lane : 0) * p.stride_list;
+    const bool live = lane < p.n_lists;
+    int pos = 0;
+    u64 cur = live ? lst[0] : KEY_PAD;
+    u64 nxt = (live && k > 1) ? lst[1] : KEY_PAD;
+    for (int r = 0; r < k; r++) {
+        const u64 m = wave_min_u64(cur);
+        const size_t o = (size_t)q * k + r;
+        if (m == KEY_PAD) {
+            if (lane == 0) emit_result(p, o, KEY_PAD);
+        } else if (cur == m) {
+            emit_result(p, o, m);
+            pos++;
+            cur = nxt;
+            nxt = pos + 1 < k ? lst[pos + 1] : KEY_PAD;
         }
     }
 }
