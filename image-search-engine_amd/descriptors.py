@@ -26,7 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from .config import Config, DnnModels
-from .resnet import resnet50_features
+from .resnet import fold_batchnorm_, resnet50_features
 from .utils import chunkIt
 
 config = Config()
@@ -49,12 +49,13 @@ class CNNDescriptor:
     """
 
     def __init__(self, model=DnnModels.RESNET, seed: int = 0, out_dim: int | None = None,
-                 device: str | None = None, dtype: torch.dtype = torch.float32):
+                 device: str | None = None, dtype: torch.dtype = torch.float32, fold_bn: bool = True):
         self.model = model
         self.seed = seed
         self.out_dim = out_dim
         self.device = torch.device(device or config.DEVICE)
         self.dtype = dtype
+        self.fold_bn = fold_bn  # inference only: BatchNorm folded into the convolutions
         self.preprocessor = None
         self.feature_extractor = None
         self.projection = None
@@ -64,6 +65,8 @@ class CNNDescriptor:
         if self.model == DnnModels.RESNET:
             self.preprocessor = self._preprocess_batch
             net = resnet50_features(self.seed)
+            if self.fold_bn:
+                net = fold_batchnorm_(net)
             self.feature_extractor = net.to(self.device).to(memory_format=torch.channels_last)
             if self.out_dim is not None and self.out_dim != 2048:
                 g = torch.Generator().manual_seed(self.seed + 1)

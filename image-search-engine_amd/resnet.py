@@ -85,3 +85,21 @@ def resnet50_features(seed: int | None = 0) -> ResNet50Features:
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
         return ResNet50Features()
+
+
+def fold_batchnorm_(net: ResNet50Features) -> ResNet50Features:
+    """Inference-only: fold every BatchNorm into the convolution in front of it (eval-mode
+    statistics), in place.  Same function up to fp32 rounding, one elementwise pass less per layer."""
+    from torch.nn.utils.fusion import fuse_conv_bn_eval
+
+    net.eval()
+    net.conv1 = fuse_conv_bn_eval(net.conv1, net.bn1)
+    net.bn1 = nn.Identity()
+    for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        for blk in layer:
+            blk.conv1, blk.bn1 = fuse_conv_bn_eval(blk.conv1, blk.bn1), nn.Identity()
+            blk.conv2, blk.bn2 = fuse_conv_bn_eval(blk.conv2, blk.bn2), nn.Identity()
+            blk.conv3, blk.bn3 = fuse_conv_bn_eval(blk.conv3, blk.bn3), nn.Identity()
+            if blk.downsample is not None:
+                blk.downsample = nn.Sequential(fuse_conv_bn_eval(blk.downsample[0], blk.downsample[1]))
+    return net
