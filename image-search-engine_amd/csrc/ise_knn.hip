@@ -457,18 +457,24 @@ static void launch_one(dim3 grid, size_t lds, hipStream_t st, const ScanParams& 
 template <int W, int T, bool BF16, bool SHIFT>
 static void launch_scan_ch(int ch, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     switch (ch) {
-        case 8: launch_one<8, W, T, BF16, SHIFT>(grid, lds, st, sp); break;
+        case 8:  // 16-wave blocks never use 8-step chunks (register budget)
+            if constexpr (W < 16) launch_one<8, W, T, BF16, SHIFT>(grid, lds, st, sp);
+            else launch_one<4, W, T, BF16, SHIFT>(grid, lds, st, sp);
+            break;
         case 4: launch_one<4, W, T, BF16, SHIFT>(grid, lds, st, sp); break;
         case 2: launch_one<2, W, T, BF16, SHIFT>(grid, lds, st, sp); break;
         default: launch_one<1, W, T, BF16, SHIFT>(grid, lds, st, sp); break;
     }
 }
-// variants built: (waves, T) in {(8,1), (4,1), (8,2), (8,3)}; 4 waves exist for one query
-// tile only (long rows, where 8 waves' lists no longer fit beside the tile)
+// variants built: (waves, T) in {(8,1), (4,1), (16,2), (8,2), (8,3), (8,4 bf16)}; 4 waves exist for
+// one query tile only (long rows, where 8 waves' lists no longer fit beside the tile); two query
+// tiles run one 16-wave block per CU when the lists fit (more waves to hide the bookkeeping
+// behind: 430 -> 407 us at 1M x 512, 85 -> 71 us at 125k)
 template <bool BF16, bool SHIFT>
 static void launch_scan_v(int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     if (T == 1 && waves == 4) launch_scan_ch<4, 1, BF16, SHIFT>(ch, grid, lds, st, sp);
     else if (T == 1) launch_scan_ch<8, 1, BF16, SHIFT>(ch, grid, lds, st, sp);
+    else if (T == 2 && waves == 16) launch_scan_ch<16, 2, BF16, SHIFT>(ch, grid, lds, st, sp);
     else if (T == 2) launch_scan_ch<8, 2, BF16, SHIFT>(ch, grid, lds, st, sp);
     else if (T == 3) launch_scan_ch<8, 3, BF16, SHIFT>(ch, grid, lds, st, sp);
     else if constexpr (BF16) launch_scan_ch<8, 4, true, false>(ch, grid, lds, st, sp);  // 64 queries per pass: bf16 rows only
@@ -512,6 +518,10 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     for (int t = 1; t <= tmax; t++) {
         int wv = 0;
         size_t lds = 0;
+        if (t == 2 && scan_lds_bytes(h, 16, 2, pl->kb) <= LDS_LIMIT) {  // 16 waves: two tiles only
+            wv = 16;
+            lds = scan_lds_bytes(h, 16, 2, pl->kb);
+        }
         for (int cand_w = 8; cand_w >= (t == 1 ? 4 : 8) && !wv; cand_w -= 4) {  // 4 waves: one tile only
             lds = scan_lds_bytes(h, cand_w, t, pl->kb);
             if (lds <= LDS_LIMIT) wv = cand_w;
@@ -528,7 +538,7 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     if (!pl->T) return fail(ISE_E_INVALID, "d too large: a 16-query tile must fit the 160 KiB LDS (d <= ~2400)");
     // one query tile runs 16 waves per CU at <= 128 VGPRs: 4-step chunks (2 x 4 KB in flight per
     // wave) measured faster than 8-step ones there (no spills, more waves' worth of loads)
-    if (pl->T == 1 && pl->ch > 4) pl->ch = 4;
+    if ((pl->T == 1 || pl->waves == 16) && pl->ch > 4) pl->ch = 4;  // both run at <= 128 VGPRs
     pl->tiles_total = (int)((h->n + 15) / 16);
     int blocks_per_cu = (pl->T == 1 && pl->lds <= LDS_LIMIT / 2) ? 2 : 1;
 #ifdef ISE_ABLATE

@@ -29,9 +29,6 @@ __device__ __forceinline__ void emit_result(const MergeParams& p, size_t o, u64 
     }
 }
 
-// Each list keeps its head AND the element behind it in registers: when a head wins, the next one
-// is already there and the load of the one after is issued without being waited for, so a round
-// costs a reduction and a barrier, not an L2 round trip.
 __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams p) {
     __shared__ u64 wmin[2][MERGE_THREADS / 64];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -39,14 +36,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
     const u64* base = p.lists + (size_t)(q / p.qt) * p.stride_qtile + (size_t)(q % p.qt) * k;
     const u64* lst[MERGE_LPT];
     int pos[MERGE_LPT];
-    u64 cur[MERGE_LPT], nxt[MERGE_LPT];
+    u64 cur[MERGE_LPT];
 #pragma unroll
     for (int e = 0; e < MERGE_LPT; e++) {
         const int l = tid + e * MERGE_THREADS;
         lst[e] = base + (size_t)(l < p.n_lists ? l : 0) * p.stride_list;
         pos[e] = 0;
         cur[e] = l < p.n_lists ? lst[e][0] : KEY_PAD;
-        nxt[e] = (l < p.n_lists && k > 1) ? lst[e][1] : KEY_PAD;
     }
     for (int r = 0; r < k; r++) {
         u64 m = cur[0];
@@ -67,8 +63,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
                 if (cur[e] == m) {
                     emit_result(p, o, m);
                     pos[e]++;
-                    cur[e] = nxt[e];
-                    nxt[e] = pos[e] + 1 < k ? lst[e][pos[e] + 1] : KEY_PAD;
+                    cur[e] = pos[e] < k ? lst[e][pos[e]] : KEY_PAD;
                 }
         }
     }

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     // ---- register ring of R index chunks (CH k-steps x 16 rows each).  Chunk positions
     // run tile-major over this wave's row tiles (t0 + w, + W, ...).  The first R - 1
     // chunks are requested now: their HBM latency overlaps the rest of the staging.
-    constexpr int R = T == 1 ? 2 : (T == 2 ? 4 : (T == 3 ? 3 : 2));
+    constexpr int R = (T == 1 || W >= 16) ? 2 : (T == 2 ? 4 : (T == 3 ? 3 : 2));
     const bool has_work = (t0 + w) < t1 && !ABL(16);
     f32x4 A[R][CH];
     int ltile = t0 + w, ls0 = 0;  // position of the next chunk to LOAD (clamped at the end)
