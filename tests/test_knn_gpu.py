@@ -417,3 +417,49 @@ def test_shape_sweep_against_oracle(faiss):
             assert_knn_matches(D, I, D_ref, I_ref, xb, xq, metric, gap=ko.kth_gap(xb, xq, k, metric))
         except AssertionError as e:
             raise AssertionError(f"n={n} d={d} nq={nq} k={k} metric={metric}: {e}")
+
+
+@pytest.mark.parametrize("nq,k", [(40, 100), (20, 33), (50, 70)])
+def test_large_k_with_several_query_tiles(faiss, nq, k):
+    """k > 32 (floor-keyed passes) combined with 2 and 3 query tiles per pass."""
+    rng = np.random.default_rng(nq * k)
+    xb = rng.random((6000, 72), dtype=np.float32)
+    xq = rng.random((nq, 72), dtype=np.float32)
+    for metric in (L2, IP):
+        index = make_index(faiss, metric, 72)
+        index.add(xb)
+        D, I = index.search(xq, k)
+        D_ref, I_ref = ko.knn_exact(xb, xq, k, metric)
+        assert_knn_matches(D, I, D_ref, I_ref, xb, xq, metric, gap=ko.kth_gap(xb, xq, k, metric))
+
+
+def test_streams_and_threads_stress(faiss):
+    """Several host threads, each on its own HIP stream, hammer one index through the device API:
+    the event-ordered workspace slots must keep every batch's result intact."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    xb = rng.random((50_000, 128), dtype=np.float32)
+    index = faiss.IndexFlatL2(128)
+    index.add(xb)
+    qs = [rng.random((nq, 128), dtype=np.float32) for nq in (1, 16, 17, 33, 48, 64)]
+    refs = [ko.knn_exact(xb, q, 7, L2) for q in qs]
+    errors = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            tq = torch.from_numpy(qs[i]).cuda()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st):
+                for _ in range(30):
+                    D, I = index.search_torch(tq, 7)
+            st.synchronize()
+            assert_knn_matches(D.cpu().numpy(), I.cpu().numpy(), refs[i][0], refs[i][1], xb, qs[i], L2)
+        except Exception as e:  # surfaced in the main thread
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(qs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
