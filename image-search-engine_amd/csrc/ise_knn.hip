@@ -540,7 +540,7 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     // wave) measured faster than 8-step ones there (no spills, more waves' worth of loads)
     if ((pl->T == 1 || pl->waves == 16) && pl->ch > 4) pl->ch = 4;  // both run at <= 128 VGPRs
     pl->tiles_total = (int)((h->n + 15) / 16);
-    int blocks_per_cu = (pl->T == 1 && pl->lds <= LDS_LIMIT / 2) ? 2 : 1;
+    int blocks_per_cu = (pl->T == 1 && pl->waves <= 8 && pl->lds <= LDS_LIMIT / 2) ? 2 : 1;
 #ifdef ISE_ABLATE
     if (const char* e = getenv("ISE_PLAN")) {  // dev: "waves,blocks_per_cu" (T = 1 only)
         int wv = 8, bpc = 2;
