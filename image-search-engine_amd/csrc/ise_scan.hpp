@@ -1,24 +1,8 @@
 // ise_scan.hpp -- the streaming distance + top-k kernel (see ise_knn.hip for the overview).
 #pragma once
 #include "ise_common.hpp"
+#include "ise_scan_params.hpp"
 
-// ---------------------------------------------------------------- scan kernel
-struct ScanParams {
-    const void* xb;      // [cap][dp] float32 or bf16 rows; 16-byte "slots": row_slots per row
-    const float* norms;  // [cap]
-    const float* q;      // [nq][d]
-    const float* mu;     // [dp] shift vector (zero padded), used by SHIFT kernels
-    const u64* floor_keys;  // optional [nq]: only keys > floor enter (k > 64 passes)
-    u64* part;           // [nqt][nb][16 T][k]
-    long long n;         // rows in the index
-    int d, dp, qs_stride;  // qs_stride: LDS query row stride in 4-byte units (floats, or bf16 pairs)
-    int row_slots;         // 16-byte slots per index row = dp * elem_size / 16; one k-step = 4 slots
-    int nq, k, kb, metric;  // kb: block-list slots per query (16 or 32, >= k)
-    uint32_t id_base;
-    int tiles_total, tiles_per_block;
-    int ablate;  // dev builds (-DISE_ABLATE): bit mask of phases to skip, from $ISE_ABLATE
-    unsigned long long* stamps;  // dev builds: [blocks][waves][16] stamps (0-7 s_memrealtime 100 MHz, 8-9 s_memtime), or null
-};
 #ifdef ISE_ABLATE
 #define ABL(bit) (p.ablate & (bit))
 #define STAMP(i)                                                                                   \
@@ -36,11 +20,6 @@ struct ScanParams {
 #define STAMP(i) do {} while (0)
 #define CSTAMP(i) do {} while (0)
 #endif
-
-#define TAU0 ((u64)0xFF7FFFFFu << 32) /* ord(FLT_MAX) << 32: strict gate score < FLT_MAX */
-#define CAP 16       /* slots of a wave's private candidate list; folded out at MERGE_TRIG */
-#define MERGE_TRIG 12
-#define KB_MAX 32    /* block-list slots per query (runtime kb = 16 or 32), >= k of one pass */
 
 // ---- wave-level selection primitives on 64-bit keys.  Keys are held as
 // kk[e] = element (lane + 64 e), e < KPL; KEY_PAD = empty slot; elements with
@@ -197,14 +176,6 @@ __device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, i
     }
     if (cnt >= kmin) *cut = P;
     return cnt;
-}
-
-// LDS bytes of one scan block (host and device agree through this function)
-__host__ __device__ constexpr size_t scan_lds_layout(int S, int waves, int T, int kb) {
-    return (size_t)S * 4 /* mus: the shift vector, laid out like one query row */ +
-           (size_t)(16 * T) * ((size_t)S * 4 + 4 /* qs, xn */ + 8 /* tauS */ + 8 /* bwc, lockS */ +
-                               (size_t)waves * 4 /* cntS */ + (size_t)kb * 8 /* bootw */ +
-                               (size_t)waves * CAP * 8 /* cand; boot staging aliases it */);
 }
 
 // CH : k-steps (16 floats each) per register chunk; dp/16 is a multiple of CH

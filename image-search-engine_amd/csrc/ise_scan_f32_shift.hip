@@ -1,0 +1,6 @@
+// scan_kernel family: float32 rows, centred L2 (SHIFT).  Own translation unit so the families compile in parallel.
+#include "ise_scan_launch.hpp"
+
+void ise_launch_scan_f32_shift(int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
+    launch_scan_v<false, true>(ch, waves, T, grid, lds, st, sp);
+}
