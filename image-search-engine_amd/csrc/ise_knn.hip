@@ -67,9 +67,10 @@ struct ise_index {
     float* norms = nullptr;
     float* mu = nullptr;       // [dp] shift vector (fp32 L2 only), zero until shift_set
     bool shift_set = false;    // fixed once: at the first add, or by ise_index_set_shift before it
-    // workspaces (grown lazily, guarded by mu): calls rotate through NWS slots and a
-    // slot's reuse is ordered behind its previous use with an event, so searches on
-    // different streams may be in flight together
+    // workspaces (grown lazily, guarded by mu): NWS slots, so searches on different streams
+    // may be in flight together.  A stream keeps the slot it used last (stream order is all
+    // the ordering that needs); a stream without one takes a fresh slot, or the least
+    // recently taken one behind an event wait
     struct WorkSlot {
         u64* part = nullptr;
         size_t part_elems = 0;
@@ -77,8 +78,9 @@ struct ise_index {
         size_t keys_tmp_elems = 0;
         hipEvent_t done = nullptr;
         bool used = false;
+        hipStream_t last_stream = nullptr;  // valid when used
     };
-    static constexpr int NWS = 4;
+    static constexpr int NWS = 8;
     WorkSlot ws[NWS];
     unsigned ws_next = 0;
     // host-API staging
@@ -589,15 +591,22 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     ScanPlan pl;
     int rc = make_plan(h, nq, k, &pl);
     if (rc) return rc;
-    ise_index::WorkSlot* w = &h->ws[h->ws_next++ % ise_index::NWS];
+    ise_index::WorkSlot* w = nullptr;
+    bool same_stream = false;
+    for (auto& s : h->ws)
+        if (s.used && s.last_stream == st) { w = &s; same_stream = true; break; }
+    if (!w)
+        for (auto& s : h->ws)
+            if (!s.used) { w = &s; break; }
+    if (!w) w = &h->ws[h->ws_next++ % ise_index::NWS];
     rc = ensure_workspace(w, pl, nq, k);
     if (rc) return rc;
-    if (w->used) HIP_TRY(hipStreamWaitEvent(st, w->done, 0));
-    struct Release {  // whatever path returns, later users of the slot wait for this call
+    if (w->used && !same_stream) HIP_TRY(hipStreamWaitEvent(st, w->done, 0));
+    struct Release {  // whatever path returns, a later user on another stream waits for this call
         ise_index::WorkSlot* w;
         hipStream_t st;
         ~Release() {
-            if (hipEventRecord(w->done, st) == hipSuccess) w->used = true;
+            if (hipEventRecord(w->done, st) == hipSuccess) { w->used = true; w->last_stream = st; }
         }
     } release{w, st};
 

@@ -7,6 +7,13 @@ row ids in the low word) -> ONE all-gather (8*nq*k bytes per rank, latency
 bound) -> k-way merge on every rank.  There is no other collective on the data
 path; ``add`` is row-parallel.
 
+``ShardedIndexFlat.search`` is the one-batch form.  A server that has several
+query batches in flight uses ``SearchPipeline``: the shard scans of ``depth``
+consecutive batches share ONE all-gather and one merge (a bucketed collective,
+each bucket on its own HIP stream), so the exchange costs one launch per bucket
+instead of one per batch -- at 8 GPUs a 1M x 512 shard scan is 40 us, less than
+the host cost of issuing a collective.
+
 The reference itself never shards (single in-RAM IndexFlat, backend/utils.py:327);
 what it pins is only the result: identical to one unsharded index.
 """
@@ -51,11 +58,16 @@ class HipShardBackend:
         return self._fc.merge_keys_torch(keys_all, self.metric)
 
     # allocation-free forms (caller-owned buffers, work enqueued on the current stream)
-    def local_search_keys_into(self, xq: torch.Tensor, k: int, id_base: int, keys: torch.Tensor) -> None:
-        self.index.search_keys_into(xq, k, id_base, keys, torch.cuda.current_stream(self.device).cuda_stream)
+    # (``stream``: a raw hipStream_t handle; default = torch's current stream)
+    def local_search_keys_into(self, xq: torch.Tensor, k: int, id_base: int, keys: torch.Tensor, stream=None) -> None:
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.index.search_keys_into(xq, k, id_base, keys, stream)
 
-    def merge_into(self, keys_all: torch.Tensor, D: torch.Tensor, I: torch.Tensor) -> None:
-        self._fc.merge_keys_into(keys_all, self.metric, D, I, torch.cuda.current_stream(self.device).cuda_stream)
+    def merge_into(self, keys_all: torch.Tensor, D: torch.Tensor, I: torch.Tensor, stream=None) -> None:
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._fc.merge_keys_into(keys_all, self.metric, D, I, stream)
 
 
 class ShardedIndexFlat:
@@ -146,3 +158,124 @@ class ShardedIndexFlat:
     def search(self, xq: torch.Tensor, k: int):
         """(D, I) identical on every rank and identical to an unsharded IndexFlat."""
         return self.search_end(self.search_begin(xq, k))
+
+
+class SearchPipeline:
+    """Batches in flight over a ``ShardedIndexFlat``, ``depth`` batches per all-gather.
+
+    ``submit(xq)`` enqueues the shard-local scan of one batch of exactly ``nq`` queries; every
+    ``depth``-th submit closes the bucket: ONE all-gather of the bucket's packed candidates
+    ([world][depth*nq][k] keys) and one merge.  A bucket lives on one HIP stream from its first scan
+    to its merge, and ``buckets`` buckets (a ring of buffer sets, one stream each) are in flight, so
+    the exchange of one bucket overlaps the scans of the next ones without any cross-stream event
+    on the per-batch path.  Results come back one bucket late (so that waiting for them never
+    stalls the scans being issued) as a list of ``(D, I)`` per batch, in submit order; ``flush()``
+    closes a partial bucket and returns everything outstanding.  Returned tensors are views into
+    the ring and stay valid until ``buckets - 1`` further buckets have been closed; they are
+    ordered after their producer on the caller's current stream.
+
+    ``submit(xq, xq_ready=True)`` skips ordering the scan after the caller's current stream: for
+    query tensors that are already materialised (e.g. resident inputs, or produced before a
+    synchronize).
+
+    Every rank must submit the same sequence of batches (the all-gathers pair up by order).
+    On a CPU process group (the gloo tests) the same code runs synchronously without streams.
+    """
+
+    def __init__(self, index: "ShardedIndexFlat", nq: int, k: int, depth: int = 4, buckets: int = 4):
+        if depth < 1 or buckets < 2:
+            raise ValueError("SearchPipeline needs depth >= 1 and buckets >= 2")
+        self.index, self.nq, self.k, self.depth, self.nbuckets = index, int(nq), int(k), int(depth), int(buckets)
+        self.dev = getattr(index.backend, "device", torch.device("cpu"))
+        self.cuda = self.dev.type == "cuda"
+        self.into = hasattr(index.backend, "local_search_keys_into")
+        world = index.world
+        self.sets = []
+        per = self.nq * self.k
+        for _ in range(self.nbuckets):
+            keys = torch.empty((self.depth, self.nq, self.k), dtype=torch.int64, device=self.dev)
+            gathered = torch.empty(world * self.depth * per, dtype=torch.int64, device=self.dev)
+            D = torch.empty((self.depth * self.nq, self.k), dtype=torch.float32, device=self.dev)
+            I = torch.empty((self.depth * self.nq, self.k), dtype=torch.int64, device=self.dev)
+            # every view the hot loop needs is made once here (a tensor view costs microseconds)
+            b = {"keys": keys, "gathered": gathered, "D": D, "I": I, "filled": 0, "merged": 0,
+                 "keys_g": [keys[g] for g in range(self.depth)],
+                 "full": (keys.view(-1), gathered, gathered.view(world, self.depth * self.nq, self.k), D, I),
+                 "out": [(D[g * self.nq:(g + 1) * self.nq], I[g * self.nq:(g + 1) * self.nq])
+                         for g in range(self.depth)]}
+            if self.cuda:
+                b["stream"] = torch.cuda.Stream(device=self.dev)
+                b["handle"] = b["stream"].cuda_stream
+                b["ready"] = torch.cuda.Event()
+                b["done"] = torch.cuda.Event()
+            self.sets.append(b)
+        self.cur = 0          # set being filled
+        self.undelivered = []  # closed buckets whose results have not been handed back, oldest first
+
+    def submit(self, xq: torch.Tensor, xq_ready: bool = False):
+        if xq.shape[0] != self.nq or xq.shape[1] != self.index.d:
+            raise ValueError(f"SearchPipeline was built for batches of shape ({self.nq}, {self.index.d})")
+        b = self.sets[self.cur]
+        g = b["filled"]
+        be = self.index.backend
+        if self.cuda:
+            if not xq_ready:  # order the scan after whatever produced xq
+                b["ready"].record(torch.cuda.current_stream(self.dev))
+                b["stream"].wait_event(b["ready"])
+            be.local_search_keys_into(xq, self.k, self.index.id_base, b["keys_g"][g], b["handle"])
+        elif self.into:
+            be.local_search_keys_into(xq, self.k, self.index.id_base, b["keys_g"][g])
+        else:
+            b["keys_g"][g].copy_(be.local_search_keys(xq, self.k, self.index.id_base))
+        b["filled"] = g + 1
+        if b["filled"] == self.depth:
+            return self._close()
+        return []
+
+    def flush(self):
+        out = self._close() if self.sets[self.cur]["filled"] else []
+        return out + self._deliver(keep=0)
+
+    # -- one bucket: all-gather + merge, on the bucket's stream behind its scans
+    def _close(self):
+        b = self.sets[self.cur]
+        m = b["filled"]
+        world, per = self.index.world, self.nq * self.k
+        if m == self.depth:
+            keys, gathered, g3, D, I = b["full"]
+        else:  # partial bucket (flush): prefixes of the same buffers
+            keys = b["keys"].view(-1)[: m * per]
+            gathered = b["gathered"][: world * m * per]
+            g3 = gathered.view(world, m * self.nq, self.k)
+            D, I = b["D"][: m * self.nq], b["I"][: m * self.nq]
+        be = self.index.backend
+        if self.cuda:
+            prev = torch.cuda.current_stream(self.dev)
+            torch.cuda.set_stream(b["stream"])  # the process group orders the collective after this stream
+            try:
+                dist.all_gather_into_tensor(gathered, keys, group=self.index.group)
+                be.merge_into(g3, D, I, b["handle"])
+            finally:
+                torch.cuda.set_stream(prev)
+            b["done"].record(b["stream"])
+        else:
+            dist.all_gather_into_tensor(gathered, keys, group=self.index.group)
+            if hasattr(be, "merge_into"):
+                be.merge_into(g3, D, I)
+            else:
+                Dm, Im = be.merge(g3)
+                D.copy_(Dm)
+                I.copy_(Im)
+        b["merged"], b["filled"] = m, 0
+        self.undelivered.append(self.cur)
+        self.cur = (self.cur + 1) % self.nbuckets
+        return self._deliver(keep=1)
+
+    def _deliver(self, keep: int):
+        out = []
+        while len(self.undelivered) > keep:
+            b = self.sets[self.undelivered.pop(0)]
+            if self.cuda:
+                torch.cuda.current_stream(self.dev).wait_event(b["done"])
+            out += b["out"][: b["merged"]]
+        return out

@@ -80,6 +80,27 @@ def _worker(rank, world, port, metric, n, q):
         D1, I1 = idx.search_end(t1)
         D2, I2 = idx.search_end(t2)
         assert np.array_equal(I1.numpy(), Ir) and np.array_equal(I2.numpy(), Ir[:2])
+        # bucketed pipeline: 3 batches per all-gather, 2 buffer sets, 8 distinct batches
+        # (two full buckets + a partial one closed by flush); results in submit order
+        from image_search_engine_amd.sharded import SearchPipeline
+
+        nqp = xq.shape[0]
+        batches = [np.ascontiguousarray(np.roll(xq, s, axis=0) * np.float32(1 + 0.125 * (s % 3))) for s in range(8)]
+        pipe = SearchPipeline(idx, nqp, k, depth=3, buckets=2)
+        got, when = [], []
+        for i, bq in enumerate(batches):
+            out = pipe.submit(torch.from_numpy(bq))
+            got += [(Dg.clone(), Ig.clone()) for Dg, Ig in out]
+            when.append(len(got))
+        assert when == [0, 0, 0, 0, 0, 3, 3, 3], when  # a bucket is handed back when the next one closes
+        got += [(Dg.clone(), Ig.clone()) for Dg, Ig in pipe.flush()]
+        assert len(got) == len(batches)
+        for bq, (Dg, Ig) in zip(batches, got):
+            Db, Ib = ko.knn_exact(xb, bq, k, metric)
+            assert np.array_equal(Ig.numpy(), Ib) and np.array_equal(Dg.numpy(), Db)
+        assert pipe.flush() == []
+        with pytest.raises(ValueError):
+            pipe.submit(tq[:1])
         # every rank holds the same answer
         allI = [torch.empty_like(I) for _ in range(world)]
         dist.all_gather(allI, I)
