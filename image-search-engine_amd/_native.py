@@ -54,6 +54,7 @@ PROTOTYPES = [
     ("ise_merge_keys_device", _int, [_vp, _int, _i64, _int, _int, _vp, _vp, _int, _vp]),
     ("ise_normalize_rows_device", _int, [_vp, _i64, _int, _int, _vp]),
     ("ise_normalize_rows_host", _int, [_vp, _i64, _int, _int]),
+    ("ise_bovw_histogram_device", _int, [_vp, _vp, _i64, _int, _vp, _int, _vp]),
     ("ise_index_search_timed_device", _int,
      [_vp, _vp, _i64, _int, _vp, _vp, _vp, _int, _f32p, _f32p]),
 ]

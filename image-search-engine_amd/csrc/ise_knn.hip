@@ -875,6 +875,20 @@ extern "C" int ise_normalize_rows_device(float* x_dev, int64_t n, int d, int dev
     return ISE_OK;
 }
 
+extern "C" int ise_bovw_histogram_device(const int64_t* labels_dev, const int64_t* offsets_dev, int64_t n_images, int K,
+                                         double* out_dev, int device, void* stream) {
+    if (n_images < 0 || K <= 0 || (n_images > 0 && (!offsets_dev || !out_dev)))
+        return fail(ISE_E_INVALID, "bad argument");
+    if (K > HIST_K_MAX) return fail(ISE_E_INVALID, "histogram: at most 16384 bins");
+    if (n_images == 0) return ISE_OK;
+    if (n_images >= (1ll << 31)) return fail(ISE_E_INVALID, "too many images");
+    DeviceGuard gd(device);
+    hipLaunchKernelGGL(bovw_histogram_kernel, dim3((unsigned)n_images), dim3(256), (size_t)K * sizeof(unsigned int),
+                       (hipStream_t)stream, (const long long*)labels_dev, (const long long*)offsets_dev, K, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ISE_OK;
+}
+
 extern "C" int ise_normalize_rows_host(float* x, int64_t n, int d, int device) {
     if (n < 0 || d <= 0 || (n > 0 && !x)) return fail(ISE_E_INVALID, "bad argument");
     if (n == 0) return ISE_OK;

@@ -154,3 +154,70 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ x, l
         for (int j = lane; j < d; j += 64) xr[j] *= inv;
     }
 }
+
+// ---------------------------------------------------------------- visual-word histograms
+// One block per image: np.histogram(labels_of_image, bins=K) exactly as the reference's BoVW loop
+// calls it (backend/bag_of_visual_words.py:98-106) -- K equal-width bins between the image's OWN
+// smallest and largest label (no range argument), not a bincount over [0, K).  The float64
+// arithmetic follows numpy's uniform-bin path operation for operation (numpy/lib/_histograms_impl.py:
+// scale, truncate, then the two one-ulp corrections against linspace edges j*step + first), with
+// contraction off so that no multiply-add pair is fused.  Counts accumulate in LDS.
+#define HIST_K_MAX 16384
+__global__ __launch_bounds__(256) void bovw_histogram_kernel(const long long* __restrict__ labels,
+                                                             const long long* __restrict__ offsets, int K,
+                                                             double* __restrict__ out) {
+#pragma clang fp contract(off)
+    extern __shared__ unsigned int hist[];  // [K]
+    __shared__ long long red_lo[4], red_hi[4];
+    const long long img = blockIdx.x;
+    const long long b = offsets[img], e = offsets[img + 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int j = tid; j < K; j += 256) hist[j] = 0u;
+    long long lo = 0x7fffffffffffffffll, hi = -0x7fffffffffffffffll - 1;
+    for (long long i = b + tid; i < e; i += 256) {
+        const long long a = labels[i];
+        lo = a < lo ? a : lo;
+        hi = a > hi ? a : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long lo2 = __shfl_xor(lo, off), hi2 = __shfl_xor(hi, off);
+        lo = lo2 < lo ? lo2 : lo;
+        hi = hi2 > hi ? hi2 : hi;
+    }
+    if (lane == 0) { red_lo[w] = lo; red_hi[w] = hi; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        lo = red_lo[i] < lo ? red_lo[i] : lo;
+        hi = red_hi[i] > hi ? red_hi[i] : hi;
+    }
+    if (e > b) {
+        double first = (double)lo, last = (double)hi, denom;
+        if (lo == hi) {  // numpy widens an empty range by half a unit on both sides
+            first = first - 0.5;
+            last = last + 0.5;
+            denom = last - first;
+        } else {
+            denom = (double)(unsigned long long)(hi - lo);
+        }
+        const double step = (last - first) / (double)K;  // np.linspace(first, last, K + 1)
+        auto edge = [&](long long j) -> double {
+            if (j == K) return last;
+            const double t = (double)j * step;
+            return t + first;
+        };
+        for (long long i = b + tid; i < e; i += 256) {
+            const double a = (double)labels[i];
+            const double f = ((a - first) / denom) * (double)K;
+            long long idx = (long long)f;
+            if (idx == K) idx -= 1;
+            if (a < edge(idx)) idx -= 1;
+            if (a >= edge(idx + 1) && idx != K - 1) idx += 1;
+            atomicAdd(&hist[idx], 1u);
+        }
+    }
+    __syncthreads();
+    double* o = out + (size_t)img * K;
+    for (int j = tid; j < K; j += 256) o[j] = (double)hist[j];
+}

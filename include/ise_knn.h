@@ -126,6 +126,15 @@ int ise_index_assign_device(ise_index_t* h, const float* x_dev, int64_t n, float
 int ise_normalize_rows_device(float* x_dev, int64_t n, int d, int device, void* stream);
 int ise_normalize_rows_host(float* x, int64_t n, int d, int device);
 
+/* The visual-word histogram of BOVW.transform (backend/bag_of_visual_words.py:98-106): for
+ * every image i, np.histogram(labels[offsets[i] : offsets[i+1]], bins=K) -- K equal-width bins
+ * between that image's own smallest and largest label, as numpy computes it when no range is
+ * given.  labels: int64 ids from the k = 1 assignment (values in [0, 2^53)); offsets: n_images
+ * + 1 non-decreasing int64 row offsets; out: n_images x K float64 counts (the reference's
+ * np.zeros((n, K)) array).  An image without rows gives a zero row.  K <= 16384. */
+int ise_bovw_histogram_device(const int64_t* labels_dev, const int64_t* offsets_dev,
+                              int64_t n_images, int K, double* out_dev, int device, void* stream);
+
 /* measurement hook for bench.py: run the scan + merge kernels of one search
  * batch `iters` times on `stream` and return the average scan-kernel and
  * merge-kernel durations in milliseconds, measured with hipEvents recorded on

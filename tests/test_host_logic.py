@@ -72,3 +72,16 @@ def test_shard_bounds_cover_rows_exactly():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(g - 1))
             assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def test_bovw_module_surface_without_gpu():
+    """The histogram half of BOVW mirrors the reference's names; with no index it refuses
+    instead of falling back to a CPU path."""
+    from image_search_engine_amd import bag_of_visual_words as bovw
+    from image_search_engine_amd.kmeans_faiss import FaissKMeans
+
+    assert callable(bovw.create_visual_word_histogram) and callable(bovw.run_clustering)
+    b = bovw.BOVW(describer=None, n_clusters=8)
+    assert b.n_clusters == 8 and b.clusterer is None and b.descriptions is None
+    with pytest.raises(RuntimeError):
+        bovw.create_visual_word_histogram([np.zeros((3, 4), np.float32)], FaissKMeans(8), 8)

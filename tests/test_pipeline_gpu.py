@@ -183,3 +183,88 @@ def test_bench_contract_small():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(r["cpu_baseline"])
     assert r["ids_identical"] and r["recall_at_k"] == 1.0
+
+
+# ---- visual-word histograms: one batched assignment + one histogram kernel
+# against the reference's own loop -- clusterer.transform per image + np.histogram(bins=K)
+def _reference_histograms(images_descriptions, labels_per_image, K):
+    out = np.zeros((len(images_descriptions), K))
+    for i, ids in enumerate(labels_per_image):
+        out[i], _ = np.histogram(ids, bins=K)  # backend/bag_of_visual_words.py:103, no range=
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,d", [(200, 32), (4096, 128), (7, 16)])
+def test_bovw_histograms_equal_numpy_loop(K, d):
+    import image_search_engine_amd.faiss_compat as faiss
+    from image_search_engine_amd import bag_of_visual_words as bovw
+    from image_search_engine_amd.kmeans_faiss import FaissKMeans
+    from oracle import knn_oracle as ko
+
+    rng = np.random.default_rng(K)
+    cent = rng.standard_normal((K, d)).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    index = faiss.IndexFlatIP(d)
+    index.add(cent)
+    clusterer = FaissKMeans(K, index=index)
+    # ragged images: empty, one keypoint, all keypoints in one cluster, few clusters, many keypoints
+    lens = [0, 1, 5, 40, 300, 1000, 2500, 3, 0, 64]
+    images = [rng.standard_normal((m, d)).astype(np.float32) for m in lens]
+    images[2] = np.repeat(cent[K // 2][None] * 3.0, 5, axis=0)              # lo == hi
+    images[3] = cent[rng.integers(K // 3, K // 3 + 3, 40)] * 2.0             # narrow label range
+    images[7] = cent[[0, K - 1, K - 1]] * 1.5                                # hits both ends
+    H = bovw.create_visual_word_histogram(images, clusterer, K)
+    assert H.dtype == np.float64 and H.shape == (len(images), K)
+    labels = [ko.assign_nearest(X, cent) if len(X) else np.zeros((0, 1), np.int64) for X in images]
+    Href = _reference_histograms(images, labels, K)
+    assert np.array_equal(H, Href)
+    assert H.sum(axis=1).tolist() == [float(m) for m in lens]
+    # per-image transform (the reference's call pattern) gives the same labels as the batch
+    for X, lab in zip(images, labels):
+        if len(X):
+            assert np.array_equal(clusterer.transform(X), lab)
+
+
+@pytest.mark.gpu
+def test_bovw_histograms_batched_chunks_and_label_sweep(monkeypatch):
+    """Many small images across several upload batches; every (lo, hi) label span of a small
+    codebook, so every bin-edge rounding case of numpy's uniform-bin path is visited."""
+    import torch
+
+    import image_search_engine_amd.faiss_compat as faiss
+    from image_search_engine_amd import _native as _n
+    from image_search_engine_amd import bag_of_visual_words as bovw
+    from image_search_engine_amd.kmeans_faiss import FaissKMeans
+
+    K = 200
+    # the kernel alone on synthetic labels: all spans [lo, hi] with every label in between
+    spans = [(lo, hi) for lo in range(0, K, 7) for hi in range(lo, K, 5)]
+    labs = [np.arange(lo, hi + 1, dtype=np.int64) for lo, hi in spans]
+    offsets = np.zeros(len(labs) + 1, np.int64)
+    np.cumsum([len(a) for a in labs], out=offsets[1:])
+    dev = torch.device("cuda", 0)
+    lab_d = torch.from_numpy(np.concatenate(labs)).to(dev)
+    off_d = torch.from_numpy(offsets).to(dev)
+    for bins in (K, 64, 4096, 3):
+        out = torch.empty((len(labs), bins), dtype=torch.float64, device=dev)
+        _n.check(_n.lib.ise_bovw_histogram_device(lab_d.data_ptr(), off_d.data_ptr(), len(labs), bins,
+                                                  out.data_ptr(), 0, torch.cuda.current_stream(dev).cuda_stream))
+        ref = np.stack([np.histogram(a, bins=bins)[0] for a in labs]).astype(np.float64)
+        assert np.array_equal(out.cpu().numpy(), ref), bins
+
+    # batching: force several uploads
+    monkeypatch.setattr(bovw, "ROWS_PER_BATCH", 500)
+    rng = np.random.default_rng(5)
+    d = 24
+    cent = rng.standard_normal((K, d)).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    index = faiss.IndexFlatIP(d)
+    index.add(cent)
+    clusterer = FaissKMeans(K, index=index)
+    images = [rng.standard_normal((int(m), d)).astype(np.float32) for m in rng.integers(0, 300, 40)]
+    images[4] = rng.standard_normal((900, d)).astype(np.float32)  # one image larger than a batch
+    H = bovw.create_visual_word_histogram(images, clusterer, K)
+    ref = np.stack([np.histogram(clusterer.transform(X), bins=K)[0] if len(X) else np.zeros(K) for X in images])
+    assert np.array_equal(H, ref.astype(np.float64))
+    assert np.array_equal(bovw.create_visual_word_histogram([], clusterer, K), np.zeros((0, K)))
