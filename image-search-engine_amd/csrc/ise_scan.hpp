@@ -241,6 +241,10 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
         const char* base = static_cast<const char*>(p.xb) +
                            ((((size_t)tile * 16 + c) * p.row_slots + 4 * s0 + g) << 4);
         if (ABL(32)) base = static_cast<const char*>(p.xb) + (((size_t)c * p.row_slots + g) << 4);  // dev: L1-hot
+        // plain loads on purpose: non-temporal loads stream a pure read faster (7.1 vs 6.2 TB/s,
+        // scripts/microbench/read_bw.hip) but lose here (369 vs 343 us) -- a wave load covers 16 rows x
+        // 64 B, half lines whose other half the next load wants from L2
+        if (ABL(128)) return;  // dev: no index loads at all (registers keep whatever they hold)
 #pragma unroll
         for (int s = 0; s < CH; s++) a[s] = *reinterpret_cast<const f32x4*>(base + 64 * s);
     };
@@ -567,6 +571,11 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
 #pragma unroll
         for (int s = 0; s < CH; s++) {
             f32x4 bnext[T];
+            if (ABL(64)) {  // dev: no LDS reads, no MFMA -- the loaded data is only summed
+#pragma unroll
+                for (int t = 0; t < T; t++) acc0[t] += a[s];
+                continue;
+            }
             load_b(bnext, s + 1 < CH ? s0 + s + 1 : next_first_step);
             f32x4 as = a[s];
             if (SHIFT) as = as - *reinterpret_cast<const f32x4*>(mus + 4 * g + 16 * (s0 + s));

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_search_engine_amd.faiss_compat as faiss
 d, k = 512, 10
 nq = int(os.environ.get("NQ", "16"))
-names = {0: "full", 1: "no query loads", 2: "no inserts", 4: "no flush/merge", 8: "no epilogue",
+names = {0: "full", 128 | 1 | 8 | 4: "mfma+lds only, no A loads", 128 | 64 | 1 | 8 | 4: "loop skeleton only",
+         128: "no A loads, rest kept", 1 | 8 | 4 | 64: "stream only (no mfma/lds)", 64: "no mfma/lds, rest kept", 1: "no query loads", 2: "no inserts", 4: "no flush/merge", 8: "no epilogue",
          2 | 4: "no inserts+flush", 8 | 4: "no epilogue+flush", 1 | 8 | 4: "stream+mfma only", 16 | 4 | 1: "launch only",
          16: "no main loop", 16 | 4: "staging only", 32: "no HBM stream (L1-hot A)", 32 | 2 | 4: "L1-hot A, no inserts/final",
          32 | 8 | 4: "L1-hot A, mfma only"}
