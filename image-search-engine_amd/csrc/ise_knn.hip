@@ -76,6 +76,9 @@ struct ise_index {
         size_t part_elems = 0;
         u64* keys_tmp = nullptr;  // multi-pass k scratch
         size_t keys_tmp_elems = 0;
+        u64* xchg = nullptr;      // threshold-exchange entries of the scan kernel, tagged by xchg_seq
+        size_t xchg_elems = 0;
+        uint32_t xchg_seq = 0;    // bumped per scan launch: entries of older launches never match
         hipEvent_t done = nullptr;
         bool used = false;
         hipStream_t last_stream = nullptr;  // valid when used
@@ -191,6 +194,7 @@ static void free_all(ise_index* h) {
     for (auto& w : h->ws) {
         if (w.part) (void)hipFree(w.part);
         if (w.keys_tmp) (void)hipFree(w.keys_tmp);
+        if (w.xchg) (void)hipFree(w.xchg);
         if (w.done) (void)hipEventDestroy(w.done);
         w = ise_index::WorkSlot();
     }
@@ -542,6 +546,16 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
         HIP_TRY(hipMalloc(&w->part, need * sizeof(u64)));
         w->part_elems = need;
     }
+    const size_t needx = (size_t)pl.nqt * (16 * pl.T) * pl.nblocks;
+    if (needx > w->xchg_elems) {
+        if (w->xchg) (void)hipFree(w->xchg);
+        w->xchg = nullptr;
+        w->xchg_elems = 0;
+        HIP_TRY(hipMalloc(&w->xchg, needx * sizeof(u64)));
+        HIP_TRY(hipMemset(w->xchg, 0xFF, needx * sizeof(u64)));  // tag 0xFFFFFFFF is never issued
+        w->xchg_elems = needx;
+        w->xchg_seq = 0;
+    }
     if (k > pl.kpass) {
         const size_t need2 = (size_t)nq * ((size_t)k + 1 + pl.kpass);
         if (need2 > w->keys_tmp_elems) {
@@ -585,6 +599,20 @@ struct TimedOut {
     bool on = false;
 };
 
+// a launch tag no older entry of the slot's exchange buffer carries
+static int next_xchg_seq(ise_index::WorkSlot* w, hipStream_t st, uint32_t* seq) {
+    if (w->xchg_seq >= 0xFFFFFFF0u) {  // wrap: wipe the tags (stream-ordered behind the slot's last use)
+        HIP_TRY(hipMemsetAsync(w->xchg, 0xFF, w->xchg_elems * sizeof(u64), st));
+        w->xchg_seq = 0;
+    }
+    *seq = ++w->xchg_seq;
+    return ISE_OK;
+}
+static bool xchg_enabled() {  // dev knob: ISE_NO_XCHG=1 switches the threshold exchange off
+    static const bool on = [] { const char* e = getenv("ISE_NO_XCHG"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 // enqueue one search batch; outputs (D, I) and/or keys.  Nothing here blocks.
 static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k, uint32_t id_base, float* D_dev,
                           long long* I_dev, u64* keys_out, hipStream_t st, TimedOut* tm) {
@@ -616,6 +644,8 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     sp.row_slots = (int)(row_bytes(h) / 16);
     sp.nq = (int)nq; sp.k = pl.kpass; sp.kb = pl.kb; sp.metric = h->metric; sp.id_base = id_base;
     sp.tiles_total = pl.tiles_total; sp.tiles_per_block = pl.tiles_per_block;
+    sp.xchg = xchg_enabled() ? w->xchg : nullptr;
+    sp.xchg_seq = 0;
     sp.ablate = 0;
     sp.stamps = nullptr;
 #ifdef ISE_ABLATE
@@ -632,6 +662,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     const dim3 grid((unsigned)pl.nblocks, (unsigned)pl.nqt);
     if (k <= pl.kpass) {
         mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out;
+        if ((rc = next_xchg_seq(w, st, &sp.xchg_seq))) return rc;
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
         launch_scan(h, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
@@ -649,6 +680,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     for (int off = 0; off < k; off += pl.kpass) {
         sp.floor_keys = off ? floor_dev : nullptr;
         mp.D = nullptr; mp.I = nullptr; mp.keys_out = pass_keys;
+        if ((rc = next_xchg_seq(w, st, &sp.xchg_seq))) return rc;
         launch_scan(h, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);

@@ -195,6 +195,13 @@ __device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, i
 //          key, so tauS tracks the block's running k-th best.
 //   final  one wave selects the exact sorted top-k of bootw + what is left in the W
 //          private lists and writes the block's list to HBM.
+//   exchange (once per block): at boot a block publishes, per query, the score of its best boot
+//          row (one 8-byte store: launch seq << 32 | ord(score)).  After its second row tile a
+//          wave reads the entries of all blocks for its queries: the k-th smallest of those scores
+//          is the k-th best of nblocks DISTINCT rows, hence an upper bound of the final k-th
+//          distance -- as tight as the k-th best of a W*16*nblocks-row sample (32k-64k rows)
+//          instead of the block's own W*16.  It only lowers tauS; entries not yet written (or of
+//          an older launch: seq mismatch) just count as absent.  No polling, no ordering needed.
 //
 // SHIFT (fp32 L2 only): distances are translation invariant, and the expanded form
 // |x|^2 + |y|^2 - 2 x.y loses digits when the rows share a large common component
@@ -204,7 +211,12 @@ __device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, i
 // (4 VALU subs per k-step), so every term is as small as the data's spread, not its
 // offset.  Rows stay stored unshifted (reconstruct / write_index are exact).
 template <int CH, int W, int T, bool BF16, bool SHIFT>
-__global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) void scan_kernel(const ScanParams p) {
+__global__ __launch_bounds__(W * 64)
+    // waves per SIMD pinned (min = max): 4 at T = 1 (two 8-wave blocks per CU, 128 VGPRs), W/4 above (one block
+    // per CU, up to 256 VGPRs).  Without the upper bound the backend's memory-bound heuristic trades the register
+    // ring for scratch to reach an occupancy the LDS footprint rules out anyway.
+    __attribute__((amdgpu_waves_per_eu(T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1), T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1))))
+    void scan_kernel(const ScanParams p) {
     static_assert(!(BF16 && SHIFT), "the shift is applied to fp32 rows only");
     constexpr int BLOCK_THREADS = W * 64;
     constexpr int NQ = 16 * T;                        // queries per block pass
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
         const int nw = wave_select<1>(kk, nb + n_, k, bootw + qq * kb, &ktau);  // nb + n_ <= kb + CAP <= 64
         if (lane == 0) {
             bwc[qq] = nw;
-            if (nw == k) tauS[qq] = ktau;  // never above the old value: the union only adds keys
+            if (nw == k) tauS[qq] = min_u64(tauS[qq], ktau);  // the exchange may have set it lower
         }
         wave_lds_fence();
         if (lane == 0) atomicExch(&lockS[qq], 0);
@@ -452,9 +464,17 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
                 kk[e] = (lane + 64 * e) < W * 16 ? boot[(size_t)qq * (W * 16) + lane + 64 * e] : KEY_PAD;
             u64 ktau = TAU0;
             const int nw = wave_cut<KPLB>(kk, W * 16, k, kb, bootw + qq * kb, &ktau);
+            u64 best = kk[0];
+#pragma unroll
+            for (int e = 1; e < KPLB; e++) best = min_u64(best, kk[e]);
+            best = wave_min_u64(best);
             if (lane == 0) {
                 bwc[qq] = nw;
                 tauS[qq] = ktau;  // TAU0 when fewer than k real keys were seen
+                if (p.xchg)
+                    __hip_atomic_store(p.xchg + ((size_t)blockIdx.y * NQ + qq) * gridDim.x + blockIdx.x,
+                                       ((u64)p.xchg_seq << 32) | (best >> 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -559,6 +579,52 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
         }
     };
 
+    // one-shot threshold exchange (see the header comment): queries w, w + W, ... of this wave.
+    // 256 slots (4 per lane) cover the grid, a slot folding G entries by their minimum; the k-th
+    // smallest slot value is found bit by bit with ballot counts (absent entries = 0xFFFFFFFF).
+    auto exchange = [&]() {
+        const int nb = (int)gridDim.x;
+        const int G = (nb + 255) >> 8;
+        for (int qq = w; qq < NQ; qq += W) {
+            const u64* src = p.xchg + ((size_t)blockIdx.y * NQ + qq) * nb;
+            auto slot_value = [&](int slot) -> uint32_t {
+                uint32_t best = 0xFFFFFFFFu;
+                for (int j = 0; j < G; j++) {
+                    const int i = slot * G + j;
+                    if (i < nb) {
+                        const u64 v = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)(v >> 32) == p.xchg_seq) best = min(best, (uint32_t)v);
+                    }
+                }
+                return best;
+            };
+            const uint32_t v0 = slot_value(lane), v1 = slot_value(lane + 64), v2 = slot_value(lane + 128),
+                           v3 = slot_value(lane + 192);
+            uint32_t prefix = 0;
+            int rank = k;  // 1-based rank of the wanted value among those matching the prefix
+            for (int b = 31; b >= 0; b--) {
+                const uint32_t hm = b == 31 ? 0u : 0xFFFFFFFFu << (b + 1);
+                auto zero_here = [&](uint32_t v) { return ((v ^ prefix) & hm) == 0u && ((v >> b) & 1u) == 0u; };
+                const int c0 = __popcll(__ballot(zero_here(v0))) + __popcll(__ballot(zero_here(v1))) +
+                               __popcll(__ballot(zero_here(v2))) + __popcll(__ballot(zero_here(v3)));
+                if (rank > c0) {
+                    rank -= c0;
+                    prefix |= 1u << b;
+                }
+            }
+            if (prefix != 0xFFFFFFFFu) {  // at least k entries of this launch were there
+                const u64 bound = ((u64)prefix << 32) | 0xFFFFFFFFull;  // every id at that score stays admissible
+                if (lane == 0) {
+                    while (atomicCAS(&lockS[qq], 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+                }
+                wave_lds_fence();
+                if (lane == 0 && bound < tauS[qq]) tauS[qq] = bound;
+                wave_lds_fence();
+                if (lane == 0) atomicExch(&lockS[qq], 0);
+            }
+        }
+    };
+
     // B operand (queries, from LDS) is software-pipelined one k-step ahead of the MFMAs
     // that consume it, across chunk boundaries too: bcur holds the B fragments of the
     // next step to be computed.
@@ -604,6 +670,8 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     // never drains the younger index loads.
     if (has_work) {
         int tile = t0 + w, s0 = 0;  // position of the chunk being COMPUTED
+        int tiles_done = 0;
+        bool exchanged = p.xchg == nullptr || ABL(256);
         load_b(bcur, 0);
         bool done = false;
         while (!done) {
@@ -618,9 +686,16 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
                     if (ns0 >= nsteps) { ns0 = 0; ntile = tile + W; }
                     compute_chunk(A[j], s0, ns0);
                     if (ns0 == 0 && !ABL(8)) epilogue(tile, yn);
+                    if (ns0 == 0) tiles_done++;
                     done = ntile >= t1;
                     tile = ntile; s0 = ns0;
                 }
+            }
+            // outside the unrolled ring steps (one copy of the code): after the wave's second row tile
+            // -- and only when enough row tiles remain for the tighter threshold to pay for the read
+            if (!exchanged && tiles_done >= 1) {
+                if (t1 - tile >= 4 * W) exchange();
+                exchanged = true;
             }
         }
     }

@@ -19,6 +19,10 @@ struct ScanParams {
     int nq, k, kb, metric;  // kb: block-list slots per query (16 or 32, >= k)
     uint32_t id_base;
     int tiles_total, tiles_per_block;
+    // one-shot threshold exchange: [nqt][16 T][nblocks] entries (launch seq << 32 | ord(score) of the
+    // block's best boot row); null = off.  See scan_kernel.
+    unsigned long long* xchg;
+    uint32_t xchg_seq;
     int ablate;  // dev builds (-DISE_ABLATE): bit mask of phases to skip, from $ISE_ABLATE
     unsigned long long* stamps;  // dev builds: [blocks][waves][16] stamps (0-7 s_memrealtime 100 MHz, 8-9 s_memtime), or null
 };
