@@ -475,8 +475,8 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
 #endif
     // relative time of one pass over the index with T query tiles (measured, 1M x 512)
     // (fp32: T = 3 is MFMA-bound; bf16 rows stay HBM-bound, the growth is top-k bookkeeping)
-    static const double pass_cost_f32[5] = {0.0, 1.0, 1.2, 1.6, 0.0};
-    static const double pass_cost_bf16[5] = {0.0, 1.0, 1.17, 1.25, 1.4};
+    static const double pass_cost_f32[5] = {0.0, 1.0, 1.16, 1.43, 0.0};
+    static const double pass_cost_bf16[5] = {0.0, 1.0, 1.07, 1.16, 1.25};
     const bool bf16 = h->storage == ISE_STORE_BF16;
     const double* pass_cost = bf16 ? pass_cost_bf16 : pass_cost_f32;
     int tmax = bf16 ? 4 : 3;
@@ -553,6 +553,7 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
         w->xchg_elems = 0;
         HIP_TRY(hipMalloc(&w->xchg, needx * sizeof(u64)));
         HIP_TRY(hipMemset(w->xchg, 0xFF, needx * sizeof(u64)));  // tag 0xFFFFFFFF is never issued
+        HIP_TRY(hipStreamSynchronize(nullptr));  // the fill is done before any stream's launch reads it
         w->xchg_elems = needx;
         w->xchg_seq = 0;
     }

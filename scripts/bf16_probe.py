@@ -8,7 +8,7 @@ n = int(os.environ.get("N", "1000000"))
 xb = torch.nn.functional.normalize(torch.randn((n, d), device="cuda"), dim=1)
 exact = faiss.IndexFlatIP(d); exact.add_torch(xb)
 approx = faiss.IndexFlatIP(d, storage="bf16"); approx.add_torch(xb)
-for nq in (16, 32, 48, 96, 1024):
+for nq in (16, 32, 48, 64, 96, 128, 1024):
     xq = torch.nn.functional.normalize(torch.randn((nq, d), device="cuda"), dim=1)
     D0, I0 = exact.search_torch(xq, k)
     D1, I1 = approx.search_torch(xq, k)
