@@ -195,8 +195,8 @@ __device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, i
 //          key, so tauS tracks the block's running k-th best.
 //   final  one wave selects the exact sorted top-k of bootw + what is left in the W
 //          private lists and writes the block's list to HBM.
-//   exchange (once per block): at boot a block publishes, per query, the score of its best boot
-//          row (one 8-byte store: launch seq << 32 | ord(score)).  After its second row tile a
+//   exchange (T >= 3 only, once per block): at boot a block publishes, per query, the score of its best boot
+//          row (one 8-byte store: launch seq << 32 | ord(score)).  After its first row tile a
 //          wave reads the entries of all blocks for its queries: the k-th smallest of those scores
 //          is the k-th best of nblocks DISTINCT rows, hence an upper bound of the final k-th
 //          distance -- as tight as the k-th best of a W*16*nblocks-row sample (32k-64k rows)
@@ -211,14 +211,13 @@ __device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, i
 // (4 VALU subs per k-step), so every term is as small as the data's spread, not its
 // offset.  Rows stay stored unshifted (reconstruct / write_index are exact).
 template <int CH, int W, int T, bool BF16, bool SHIFT>
-__global__ __launch_bounds__(W * 64)
-    // waves per SIMD pinned (min = max): 4 at T = 1 (two 8-wave blocks per CU, 128 VGPRs), W/4 above (one block
-    // per CU, up to 256 VGPRs).  Without the upper bound the backend's memory-bound heuristic trades the register
-    // ring for scratch to reach an occupancy the LDS footprint rules out anyway.
-    __attribute__((amdgpu_waves_per_eu(T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1), T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1))))
-    void scan_kernel(const ScanParams p) {
+__global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) void scan_kernel(const ScanParams p) {
     static_assert(!(BF16 && SHIFT), "the shift is applied to fp32 rows only");
     constexpr int BLOCK_THREADS = W * 64;
+    // threshold exchange: compiled in from three query tiles up, where the candidate bookkeeping is what
+    // it saves (nq = 48: 560 -> 508 us); at T = 2 (16-wave blocks) the read costs more than it saves
+    // (399 -> 406 us) and at T = 1 it is neutral
+    constexpr bool XCHG = T >= 3;
     constexpr int NQ = 16 * T;                        // queries per block pass
     constexpr int TPR = BLOCK_THREADS / 16;           // threads staging one query row (per tile)
     constexpr int KPLB = (W * 16 + 63) / 64;          // boot: keys per lane
@@ -471,7 +470,7 @@ __global__ __launch_bounds__(W * 64)
             if (lane == 0) {
                 bwc[qq] = nw;
                 tauS[qq] = ktau;  // TAU0 when fewer than k real keys were seen
-                if (p.xchg)
+                if (XCHG && p.xchg)
                     __hip_atomic_store(p.xchg + ((size_t)blockIdx.y * NQ + qq) * gridDim.x + blockIdx.x,
                                        ((u64)p.xchg_seq << 32) | (best >> 32), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
@@ -671,7 +670,7 @@ __global__ __launch_bounds__(W * 64)
     if (has_work) {
         int tile = t0 + w, s0 = 0;  // position of the chunk being COMPUTED
         int tiles_done = 0;
-        bool exchanged = p.xchg == nullptr || ABL(256);
+        bool exchanged = !XCHG || p.xchg == nullptr || ABL(256);
         load_b(bcur, 0);
         bool done = false;
         while (!done) {
@@ -693,9 +692,11 @@ __global__ __launch_bounds__(W * 64)
             }
             // outside the unrolled ring steps (one copy of the code): after the wave's second row tile
             // -- and only when enough row tiles remain for the tighter threshold to pay for the read
-            if (!exchanged && tiles_done >= 1) {
-                if (t1 - tile >= 4 * W) exchange();
-                exchanged = true;
+            if constexpr (XCHG) {
+                if (!exchanged && tiles_done >= 1) {
+                    if (t1 - tile >= 4 * W) exchange();
+                    exchanged = true;
+                }
             }
         }
     }
