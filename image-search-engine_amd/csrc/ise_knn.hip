@@ -556,6 +556,8 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
         HIP_TRY(hipStreamSynchronize(nullptr));  // the fill is done before any stream's launch reads it
         w->xchg_elems = needx;
         w->xchg_seq = 0;
+        if (const char* e = getenv("ISE_XCHG_SEQ_START"))  // test knob: start near the tag wrap
+            w->xchg_seq = (uint32_t)strtoul(e, nullptr, 0);
     }
     if (k > pl.kpass) {
         const size_t need2 = (size_t)nq * ((size_t)k + 1 + pl.kpass);

@@ -463,3 +463,32 @@ def test_streams_and_threads_stress(faiss):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errors, errors
+
+
+def test_threshold_exchange_on_off_and_tag_wrap(faiss, monkeypatch):
+    """nq = 48 runs the three-tile kernel with the one-shot threshold exchange between blocks.
+    Its sequence tags start just below the wrap here (test knob), so the searches below cross the
+    point where the tags are wiped and restart; every result must stay identical to the oracle and
+    to itself."""
+    from oracle import flat_oracle as fo
+
+    monkeypatch.setenv("ISE_XCHG_SEQ_START", str(0xFFFFFFF0 - 5))
+    rng = np.random.default_rng(99)
+    n, d, nq, k = 300_000, 96, 48, 10  # enough row tiles per wave for the exchange to run
+    xb = rng.random((n, d), dtype=np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    Dr = Ir = None
+    first = None
+    for it in range(12):
+        xq = rng.random((nq, d), dtype=np.float32) if it % 3 == 0 else xq  # noqa: F821
+        D, I = index.search(xq, k)
+        if it % 3 == 0:
+            Dr, Ir, _ = fo.knn_flat(xb, xq, k, 1, 8)
+            first = (D.copy(), I.copy())
+        assert_knn_matches(D, I, Dr, Ir, xb, xq, 1)
+        assert np.array_equal(I, first[1]) and np.array_equal(D, first[0])  # bitwise repeatable
+    # large k (floor-keyed passes) through the same kernels
+    D, I = index.search(xq, 70)
+    Dr, Ir, _ = fo.knn_flat(xb, xq, 70, 1, 8)
+    assert_knn_matches(D, I, Dr, Ir, xb, xq, 1)
