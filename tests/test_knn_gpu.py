@@ -492,3 +492,34 @@ def test_threshold_exchange_on_off_and_tag_wrap(faiss, monkeypatch):
     D, I = index.search(xq, 70)
     Dr, Ir, _ = fo.knn_flat(xb, xq, 70, 1, 8)
     assert_knn_matches(D, I, Dr, Ir, xb, xq, 1)
+
+
+def test_shards_with_three_query_tiles_equal_unsharded(faiss):
+    """48 queries per pass (the kernel with the threshold exchange), shards large enough for the
+    exchange to run, global ids through id_base: merged shards == one index, bit for bit."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    n, d, nq, k = 400_000, 64, 100, 10
+    xb = rng.random((n, d), dtype=np.float32)
+    xb[n - 7] = xb[11]                       # tie across shards: lower global id first
+    xq = rng.random((nq, d), dtype=np.float32)
+    xq[0] = xb[11]
+    tq = torch.from_numpy(xq).cuda()
+    for metric in (L2, IP):
+        whole = make_index(faiss, metric, d)
+        whole.add(xb)
+        D0, I0 = whole.search(xq, k)
+        if metric == L2:
+            assert I0[0, 0] == 11 and I0[0, 1] == n - 7
+        keys = []
+        G = 2
+        for r in range(G):
+            lo, hi = n * r // G, n * (r + 1) // G
+            sh = make_index(faiss, metric, d)
+            sh.set_shift(whole.get_shift())
+            sh.add(xb[lo:hi])
+            keys.append(sh.search_keys_torch(tq, k, id_base=lo))
+        D1, I1 = faiss.merge_keys_torch(torch.stack(keys), metric)
+        assert np.array_equal(I0, I1.cpu().numpy())
+        assert np.array_equal(D0, D1.cpu().numpy())
