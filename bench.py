@@ -214,6 +214,21 @@ def main():
     alg_bytes = 4.0 * n_local * d + 4.0 * nq * d + 12.0 * nq * k
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
 
+    # per-batch latency (median + p10/p90): one batch at a time on one stream, an
+    # event pair around scan + merge.  Single-GPU runs only; the timed region above is the metric.
+    latency = None
+    if not sharded:
+        s0 = streams[0]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+        for e0, e1 in evs:
+            e0.record(s0)
+            index.search_into(xq, k, outs[0][0], outs[0][1], s0.cuda_stream)
+            e1.record(s0)
+        torch.cuda.synchronize()
+        us = np.sort(np.array([e0.elapsed_time(e1) * 1e3 for e0, e1 in evs]))
+        latency = {"p10": float(us[10]), "median": float(us[50]), "p90": float(us[90]),
+                   "what": "one batch at a time on one stream: scan + merge, HIP event pair per batch, 100 batches"}
+
     if rank == 0:
         res = {
             "metric": "queries/sec, exact brute-force L2 kNN (recall@10 vs exact CPU), 1Mx512 fp32 index, k=10",
@@ -241,6 +256,8 @@ def main():
                                              "(ise_index_search_timed_device); rocprofv3 agreement: "
                                              "profiles/r01/bench_nq16_streams1_kernel_stats.csv"},
         }
+        if latency is not None:
+            res["batch_latency_us"] = latency
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(xb_host, xq_host, k)
             res["cpu_baseline"] = cb

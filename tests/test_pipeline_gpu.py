@@ -183,6 +183,8 @@ def test_bench_contract_small():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(r["cpu_baseline"])
     assert r["ids_identical"] and r["recall_at_k"] == 1.0
+    lat = r["batch_latency_us"]
+    assert 0 < lat["p10"] <= lat["median"] <= lat["p90"]
 
 
 # ---- visual-word histograms: one batched assignment + one histogram kernel
