@@ -523,3 +523,29 @@ def test_shards_with_three_query_tiles_equal_unsharded(faiss):
         D1, I1 = faiss.merge_keys_torch(torch.stack(keys), metric)
         assert np.array_equal(I0, I1.cpu().numpy())
         assert np.array_equal(D0, D1.cpu().numpy())
+
+
+def test_benchmark_data_1000_query_sample(faiss):
+    """SURVEY.md 8d parity gate: the benchmark's own index (1M x 512 uniform[0,1), default_rng 1234)
+    against a 1000-query sample, ids identical to the CPU oracle (tie-aware), distances within
+    1e-4 * max(1, |D|).  The oracle pass is the C restatement on the host cores (~10-20 s)."""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import host_cores, make_inputs
+    from oracle import flat_oracle as fo
+
+    n, d, nq, k = 1_000_000, 512, 1000, 10
+    xb, xq = make_inputs(n, d, nq, 0, n)
+    index = faiss.IndexFlatL2(d)
+    index.add_torch(torch.from_numpy(xb).cuda())
+    D, I = index.search(xq, k)                       # host API, batches of 48 queries per pass inside
+    Dr, Ir, _ = fo.knn_flat(xb, xq, k, 1, host_cores())
+    n_mism = assert_knn_matches(D, I, Dr, Ir, xb, xq, 1)
+    assert n_mism <= 2, n_mism                      # float32 near-ties are rare on this data
+    # the device API and a second call return the same bits
+    D2, I2 = index.search_torch(torch.from_numpy(xq).cuda(), k)
+    assert np.array_equal(I, I2.cpu().numpy()) and np.array_equal(D, D2.cpu().numpy())
