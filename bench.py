@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if not 1 <= args.k <= 32:
+        raise SystemExit("bench.py times one scan pass per batch: 1 <= k <= 32 (larger k is covered by the tests)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
