@@ -461,6 +461,11 @@ struct ScanPlan {
     size_t lds;
 };
 
+static bool xchg_enabled() {  // dev knob: ISE_NO_XCHG=1 switches the threshold exchange off
+    static const bool on = [] { const char* e = getenv("ISE_NO_XCHG"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 // pick (query tiles per pass T, waves per block) for nq queries: the largest T <= 3
 // that the batch can use and whose LDS image fits, preferring 8 waves
 static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
@@ -475,7 +480,7 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
 #endif
     // relative time of one pass over the index with T query tiles (measured, 1M x 512)
     // (fp32: T = 3 is MFMA-bound; bf16 rows stay HBM-bound, the growth is top-k bookkeeping)
-    static const double pass_cost_f32[5] = {0.0, 1.0, 1.16, 1.43, 0.0};
+    static const double pass_cost_f32[5] = {0.0, 1.0, 1.11, 1.45, 0.0};
     static const double pass_cost_bf16[5] = {0.0, 1.0, 1.07, 1.16, 1.25};
     const bool bf16 = h->storage == ISE_STORE_BF16;
     const double* pass_cost = bf16 ? pass_cost_bf16 : pass_cost_f32;
@@ -488,7 +493,11 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     for (int t = 1; t <= tmax; t++) {
         int wv = 0;
         size_t lds = 0;
-        if (t == 2 && scan_lds_bytes(h, 16, 2, pl->kb) <= LDS_LIMIT) {  // 16 waves: two tiles only
+        // two tiles: 8 waves with the threshold exchange when the index is long enough for it to run and
+        // pay (>= 6 row tiles per wave: 383 vs 399 us at 1M x 512); else one 16-wave block per CU, whose
+        // extra waves hide the bookkeeping instead (71 vs 85 us at 125k rows)
+        const bool xchg_pays = xchg_enabled() && (h->n + 15) / 16 >= 6ll * 8 * h->num_cu;
+        if (t == 2 && !xchg_pays && scan_lds_bytes(h, 16, 2, pl->kb) <= LDS_LIMIT) {
             wv = 16;
             lds = scan_lds_bytes(h, 16, 2, pl->kb);
         }
@@ -610,10 +619,6 @@ static int next_xchg_seq(ise_index::WorkSlot* w, hipStream_t st, uint32_t* seq) 
     }
     *seq = ++w->xchg_seq;
     return ISE_OK;
-}
-static bool xchg_enabled() {  // dev knob: ISE_NO_XCHG=1 switches the threshold exchange off
-    static const bool on = [] { const char* e = getenv("ISE_NO_XCHG"); return !(e && e[0] == '1'); }();
-    return on;
 }
 
 // enqueue one search batch; outputs (D, I) and/or keys.  Nothing here blocks.

@@ -195,7 +195,7 @@ __device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, i
 //          key, so tauS tracks the block's running k-th best.
 //   final  one wave selects the exact sorted top-k of bootw + what is left in the W
 //          private lists and writes the block's list to HBM.
-//   exchange (T >= 3 only, once per block): at boot a block publishes, per query, the score of its best boot
+//   exchange (8-wave kernels with T >= 2, once per block): at boot a block publishes, per query, the score of its best boot
 //          row (one 8-byte store: launch seq << 32 | ord(score)).  After its first row tile a
 //          wave reads the entries of all blocks for its queries: the k-th smallest of those scores
 //          is the k-th best of nblocks DISTINCT rows, hence an upper bound of the final k-th
@@ -214,10 +214,11 @@ template <int CH, int W, int T, bool BF16, bool SHIFT>
 __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) void scan_kernel(const ScanParams p) {
     static_assert(!(BF16 && SHIFT), "the shift is applied to fp32 rows only");
     constexpr int BLOCK_THREADS = W * 64;
-    // threshold exchange: compiled in from three query tiles up, where the candidate bookkeeping is what
-    // it saves (nq = 48: 560 -> 508 us); at T = 2 (16-wave blocks) the read costs more than it saves
-    // (399 -> 406 us) and at T = 1 it is neutral
-    constexpr bool XCHG = T >= 3;
+    // threshold exchange: compiled into the 8-wave kernels with two or more query tiles, where the candidate
+    // bookkeeping is what it saves (nq = 48: 560 -> 508 us; nq = 32: 399 (16 waves) -> 383 us).  Not into the
+    // 16-wave two-tile kernel (the read costs more than it saves there: 399 -> 406 us; the host picks it
+    // for short indexes, where the exchange would not run anyway) nor at T = 1 (neutral).
+    constexpr bool XCHG = T >= 3 || (T == 2 && W == 8);
     constexpr int NQ = 16 * T;                        // queries per block pass
     constexpr int TPR = BLOCK_THREADS / 16;           // threads staging one query row (per tile)
     constexpr int KPLB = (W * 16 + 63) / 64;          // boot: keys per lane
