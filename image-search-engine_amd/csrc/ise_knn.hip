@@ -496,7 +496,8 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
         // two tiles: 8 waves with the threshold exchange when the index is long enough for it to run and
         // pay (>= 6 row tiles per wave: 383 vs 399 us at 1M x 512); else one 16-wave block per CU, whose
         // extra waves hide the bookkeeping instead (71 vs 85 us at 125k rows)
-        const bool xchg_pays = xchg_enabled() && (h->n + 15) / 16 >= 6ll * 8 * h->num_cu;
+        // (fp32 rows only: bf16 rows stay HBM-bound and run 208 vs 217 us with the 16-wave block)
+        const bool xchg_pays = !bf16 && xchg_enabled() && (h->n + 15) / 16 >= 6ll * 8 * h->num_cu;
         if (t == 2 && !xchg_pays && scan_lds_bytes(h, 16, 2, pl->kb) <= LDS_LIMIT) {
             wv = 16;
             lds = scan_lds_bytes(h, 16, 2, pl->kb);
