@@ -103,8 +103,8 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=512)
     ap.add_argument("--nq", type=int, default=16)
