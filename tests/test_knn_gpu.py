@@ -549,3 +549,41 @@ def test_benchmark_data_1000_query_sample(faiss):
     # the device API and a second call return the same bits
     D2, I2 = index.search_torch(torch.from_numpy(xq).cuda(), k)
     assert np.array_equal(I, I2.cpu().numpy()) and np.array_equal(D, D2.cpu().numpy())
+
+
+def test_streams_and_threads_stress_with_exchange(faiss):
+    """The stress test on an index long enough for the threshold exchange to run: host threads on
+    their own streams, batch sizes that use the two- and three-tile kernels (and several passes),
+    each stream's slot carrying its own exchange buffer and sequence tags."""
+    import torch
+    from oracle import flat_oracle as fo
+
+    rng = np.random.default_rng(77)
+    n, d, k = 400_000, 64, 10
+    xb = rng.random((n, d), dtype=np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    qs = [rng.random((nq, d), dtype=np.float32) for nq in (32, 48, 100, 33, 150)]
+    refs = [fo.knn_flat(xb, q, k, 1, 8)[:2] for q in qs]
+    errors = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            tq = torch.from_numpy(qs[i]).cuda()
+            torch.cuda.synchronize()
+            outs = []
+            with torch.cuda.stream(st):
+                for _ in range(15):
+                    outs.append(index.search_torch(tq, k))
+            st.synchronize()
+            for D, I in outs[::7]:
+                assert_knn_matches(D.cpu().numpy(), I.cpu().numpy(), refs[i][0], refs[i][1], xb, qs[i], L2)
+            assert all(torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][0], o[0]) for o in outs)
+        except Exception as e:  # surfaced in the main thread
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(qs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
