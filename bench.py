@@ -264,6 +264,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, d, nq, k, world),
                          "kernel": "scan_kernel", "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
                          "algorithmic_bytes": alg_bytes,
+                         # the same bytes over the measured step time (batches overlapped on the GPU):
+                         # what the whole step sustains, beside the isolated kernel's figure above
+                         "step_effective": {"achieved": alg_bytes / (el / args.steps) / 1e9,
+                                            "frac": alg_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "kernel_ms_source": "50 back-to-back launches on one stream, HIP events around the kernel "
                                              "(ise_index_search_timed_device); rocprofv3 agreement: "
                                              "profiles/r01/bench_nq16_streams1_kernel_stats.csv"},
