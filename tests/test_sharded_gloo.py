@@ -136,3 +136,27 @@ def test_world2_gloo_sharded_search_equals_unsharded(metric, n):
     [p.join(timeout=60) for p in procs]
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_world1_gloo_pipeline_depth1():
+    """A world of one, and a pipeline that closes a bucket on every batch (depth 1): the same
+    worker, so the same checks -- plus the constructor's argument checks."""
+    from image_search_engine_amd.sharded import SearchPipeline
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), 1, 1001, q))
+    p.start()
+    rank, msg = q.get(timeout=120)
+    p.join(timeout=60)
+    assert msg == "ok", msg
+
+    class _Idx:  # enough of an index for the constructor
+        world, d, backend = 1, 4, type("B", (), {"device": torch.device("cpu")})()
+
+    with pytest.raises(ValueError):
+        SearchPipeline(_Idx(), 4, 2, depth=0)
+    with pytest.raises(ValueError):
+        SearchPipeline(_Idx(), 4, 2, depth=2, buckets=1)
+    pipe = SearchPipeline(_Idx(), 4, 2, depth=1, buckets=2)
+    assert pipe.flush() == []
