@@ -53,14 +53,39 @@ def host_cores():
     return n
 
 
+PROFILE_ROUND = "r02"
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, *.hpp, the C header):
+    what a committed counter capture is tied to."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "image-search-engine_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")))
+    files.append(os.path.join(ROOT, "include", "ise_knn.h"))
+    for p in files:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(n, d, nq, k, world):
-    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/): counters cannot be read from inside the timed process."""
-    path = os.path.join(ROOT, "profiles", "r01", f"bench_nq{nq}_hbm_pmc.json")
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/bench_nq<nq>_hbm_pmc.json; counters cannot be read from inside the timed
+    process).  The capture names the kernel sources it was taken on: if they have changed since,
+    the figure is stale and None is reported instead."""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"bench_nq{nq}_hbm_pmc.json")
     if world != 1 or (n, d, k) != (1_000_000, 512, 10) or not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)["scan_kernel"]["traffic_bytes_per_launch"]
+        rec = json.load(f)
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    return rec["scan_kernel"]["traffic_bytes_per_launch"]
 
 
 def cpu_baseline(xb, xq, k, budget_s=12.0):
@@ -202,6 +227,10 @@ def main():
         def barrier():
             pass
 
+    # every workspace slot of the library is sized before the first step (a serving process does the
+    # same): no allocation, fill or device-wide synchronisation can fall into the timed region however
+    # short the warm-up is
+    local.reserve(nq, k)
     torch.cuda.synchronize()
     run(max(1, args.warmup))
     torch.cuda.synchronize()
@@ -269,22 +298,35 @@ def main():
                          "step_effective": {"achieved": alg_bytes / (el / args.steps) / 1e9,
                                             "frac": alg_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "kernel_ms_source": "50 back-to-back launches on one stream, HIP events around the kernel "
-                                             "(ise_index_search_timed_device); rocprofv3 agreement: "
-                                             "profiles/r01/bench_nq16_streams1_kernel_stats.csv"},
+                                             "(ise_index_search_timed_device); merge_kernel_ms = everything behind "
+                                             "the scan (merge + exact re-rank + the gated exact-scan launches); "
+                                             f"rocprofv3 agreement: profiles/{PROFILE_ROUND}/bench_nq16_streams1_kernel_stats.csv"},
         }
         if latency is not None:
             res["batch_latency_us"] = latency
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(xb_host, xq_host, k)
-            res["cpu_baseline"] = cb
-            # parity gate on the benchmark data itself: full-index CPU pass for the same batch
+        if not args.no_cpu_baseline:
             from oracle import flat_oracle as fo
 
-            Dc, Ic, _ = fo.knn_flat(xb_host, xq_host, k, 1, cb["cores"])
+            fo.build()
+            cores = min(fo.max_threads(), host_cores())
+            if world == 1:
+                cb = cpu_baseline(xb_host, xq_host, k)
+                res["cpu_baseline"] = cb
+                xb_full = xb_host
+            else:  # rank 0 holds one shard: the gate needs the whole index once
+                xb_full, _ = make_inputs(n, d, nq, 0, n)
+            # parity gate on the benchmark data itself, at every N: full-index CPU pass (oracle) for the
+            # batch the last timed step answered
+            Dc, Ic, _ = fo.knn_flat(xb_full, xq_host, k, 1, cores)
             In, Dn = I.cpu().numpy(), D.cpu().numpy()
             res["recall_at_k"] = float(np.mean([len(set(In[q]) & set(Ic[q])) / k for q in range(nq)]))
             res["ids_identical"] = bool(np.array_equal(In, Ic))
             res["max_abs_dist_err"] = float(np.abs(Dn - Dc).max())
+            st = local.exact_stats()
+            res["exact_path"] = {"queries_reranked": st["reranked"], "queries_sent_to_exact_scan": st["exact_scan"]}
+            if not res["ids_identical"] or not res["max_abs_dist_err"] <= 1e-4:
+                sys.stderr.write("bench.py: PARITY GATE FAILED: " + json.dumps(res) + "\n")
+                raise SystemExit(3)  # north_star: identical ids, distances within 1e-4 (fp32)
         if sharded and world == 1:
             res["config"]["workload"] += " [rehearsal: sharded code path in a world of one]"
         sys.stdout.flush()

@@ -44,6 +44,8 @@ PROTOTYPES = [
     ("ise_index_info", _int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), _i64p, ctypes.POINTER(_int)]),
     ("ise_index_set_shift", _int, [_vp, _vp]),
     ("ise_index_get_shift", _int, [_vp, _vp]),
+    ("ise_index_stats", _int, [_vp, _u64p]),
+    ("ise_index_reserve_workspaces", _int, [_vp, _i64, _int]),
     ("ise_index_add_host", _int, [_vp, _vp, _i64]),
     ("ise_index_add_device", _int, [_vp, _vp, _i64, _vp]),
     ("ise_index_reconstruct_host", _int, [_vp, _i64, _i64, _vp]),

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +21,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 #define KEY_PAD (~0ull)
+#define TAU0 ((u64)0xFF7FFFFFu << 32) /* ord(FLT_MAX) << 32: strict gate score < FLT_MAX */
 
 // ---------------------------------------------------------------- device utils
 __device__ __forceinline__ uint32_t ord_f32(float f) {

@@ -9,11 +9,13 @@
 //   xb     [cap][dp]  float32 or bf16 index rows, stored unshifted, zero padded to whole
 //                     k-steps of 64 bytes; cap is a multiple of 16 rows
 //   norms  [cap]      float32 |y - mu|^2 per row (mu = 0 for inner product / bf16)
-//   mu     [dp]       float32 shift vector of float32 L2 indexes (mean of the first rows)
+//   mu     [dp]       float32 shift vector of float32 L2 indexes (column mean of the rows)
 //   part   [nqt][nb][16 T][k] u64  per-block sorted candidate lists (workspace slot)
 //
 // Kernels
 //   scan_kernel    ise_scan.hpp    one pass over the index per 16 T queries; HBM-bound
+//   rerank / exact ise_exact.hpp   float32 L2: direct-difference re-rank + certificate (fused into
+//                                  the merge), exact fallback scan for what it cannot prove
 //   assign_kernel  ise_assign.hpp  k = 1 against a small index (centroids); MFMA-bound
 //   merge_kernel   ise_merge.hpp   k-way merge of sorted per-block / per-rank lists
 //   row helpers    ise_rows.hpp    norms, padding / bf16 conversion, normalize_L2, shift
@@ -29,6 +31,7 @@
 #include "ise_common.hpp"
 #include "ise_scan_params.hpp"
 #include "ise_assign.hpp"
+#include "ise_exact.hpp"
 #include "ise_merge.hpp"
 #include "ise_rows.hpp"
 
@@ -65,8 +68,16 @@ struct ise_index {
     long long n = 0, cap = 0;
     void* xb = nullptr;
     float* norms = nullptr;
-    float* mu = nullptr;       // [dp] shift vector (fp32 L2 only), zero until shift_set
-    bool shift_set = false;    // fixed once: at the first add, or by ise_index_set_shift before it
+    // float32 L2 indexes: shift vector mu [dp] = column mean of the rows, (re)computed lazily at the
+    // first search after the index has grown by a quarter since the last time (or pinned by
+    // ise_index_set_shift); norms [0, norms_rows) are |y - mu|^2 for the current mu.  mu only
+    // decides how tight the scan's lower bounds are -- results are exact for any mu (ise_exact.hpp)
+    float* mu = nullptr;
+    bool shift_pinned = false;
+    long long mu_rows = 0;     // rows mu was computed from (0 = not yet)
+    long long norms_rows = 0;  // rows whose norm is valid
+    unsigned long long* stats_dev = nullptr;  // [4]: reranked queries, exact-scan queries
+    unsigned long long mu_updates = 0;
     // workspaces (grown lazily, guarded by mu): NWS slots, so searches on different streams
     // may be in flight together.  A stream keeps the slot it used last (stream order is all
     // the ordering that needs); a stream without one takes a fresh slot, or the least
@@ -82,6 +93,10 @@ struct ise_index {
         u64* xchg = nullptr;      // threshold-exchange entries of the scan kernel, tagged by xchg_seq
         size_t xchg_elems = 0;
         uint32_t xchg_seq = 0;    // bumped per scan launch: entries of older launches never match
+        u64* fl_state = nullptr;  // exact path: launch seq << 32 | number of queries on the fallback list
+        int* fl_list = nullptr;   // [fl_elems] the listed queries
+        size_t fl_elems = 0;
+        uint32_t fl_seq = 0;      // bumped per rerank launch, never reset while fl_state lives
         hipEvent_t done = nullptr;
         bool used = false;
         hipStream_t last_stream = nullptr;  // valid when used
@@ -89,11 +104,18 @@ struct ise_index {
     static constexpr int NWS = 6;
     WorkSlot ws[NWS];
     unsigned ws_next = 0;
-    // host-API staging
-    hipStream_t stream = nullptr;
-    float* q_dev = nullptr;  size_t q_elems = 0;
-    float* D_dev = nullptr;  long long* I_dev = nullptr;  size_t out_elems = 0;
-    float* h_stage = nullptr;  size_t h_stage_bytes = 0;  // pinned
+    hipStream_t stream = nullptr;  // add / reconstruct / shift maintenance
+    // host-API search contexts: a caller owns one for the duration of its call
+    struct HostCtx {
+        hipStream_t stream = nullptr;
+        float* q_dev = nullptr;  size_t q_elems = 0;
+        float* D_dev = nullptr;  long long* I_dev = nullptr;  size_t out_elems = 0;
+        bool busy = false;
+    };
+    static constexpr int NHC = 4;
+    HostCtx hc[NHC];
+    std::mutex hc_mu;
+    std::condition_variable hc_cv;
     int num_cu = 256;
     std::mutex mu_;
 };
@@ -181,9 +203,12 @@ extern "C" int ise_index_create_ex(ise_index_t** out, int d, int metric, int dev
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&h->mu, (size_t)h->dp * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->mu, 0, (size_t)h->dp * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->stats_dev, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->stats_dev, 0, 4 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         if (h->stream) (void)hipStreamDestroy(h->stream);
         if (h->mu) (void)hipFree(h->mu);
+        if (h->stats_dev) (void)hipFree(h->stats_dev);
         delete h;
         return fail(ISE_E_HIP, std::string("index setup: ") + hipGetErrorString(e));
     }
@@ -198,18 +223,19 @@ static void free_all(ise_index* h) {
         if (w.part) (void)hipFree(w.part);
         if (w.keys_tmp) (void)hipFree(w.keys_tmp);
         if (w.xchg) (void)hipFree(w.xchg);
+        if (w.fl_state) (void)hipFree(w.fl_state);
+        if (w.fl_list) (void)hipFree(w.fl_list);
         if (w.done) (void)hipEventDestroy(w.done);
         w = ise_index::WorkSlot();
     }
-    if (h->q_dev) (void)hipFree(h->q_dev);
-    if (h->D_dev) (void)hipFree(h->D_dev);
-    if (h->I_dev) (void)hipFree(h->I_dev);
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    for (auto& c : h->hc) {
+        if (c.q_dev) (void)hipFree(c.q_dev);
+        if (c.D_dev) (void)hipFree(c.D_dev);
+        if (c.I_dev) (void)hipFree(c.I_dev);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+        c = ise_index::HostCtx();
+    }
     h->xb = h->norms = nullptr;
-    h->q_dev = h->D_dev = nullptr;
-    h->I_dev = nullptr;
-    h->h_stage = nullptr;
-    h->q_elems = h->out_elems = h->h_stage_bytes = 0;
     h->n = h->cap = 0;
 }
 
@@ -220,6 +246,7 @@ extern "C" int ise_index_destroy(ise_index_t* h) {
         (void)hipDeviceSynchronize();
         free_all(h);
         if (h->mu) (void)hipFree(h->mu);
+        if (h->stats_dev) (void)hipFree(h->stats_dev);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -235,7 +262,8 @@ extern "C" int ise_index_reset(ise_index_t* h) {
     if (h->norms) (void)hipFree(h->norms);
     h->xb = h->norms = nullptr;
     h->n = h->cap = 0;
-    h->shift_set = false;
+    h->shift_pinned = false;
+    h->mu_rows = h->norms_rows = 0;
     HIP_TRY(hipMemset(h->mu, 0, (size_t)h->dp * sizeof(float)));
     return ISE_OK;
 }
@@ -273,6 +301,7 @@ static int reserve_rows(ise_index* h, long long need, hipStream_t st) {
     HIP_TRY(hipMemsetAsync(nx + (size_t)h->n * rb, 0, (size_t)(want - h->n) * rb, st));
     HIP_TRY(hipMemsetAsync(nn + h->n, 0, (size_t)(want - h->n) * sizeof(float), st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (h->xb) HIP_TRY(hipDeviceSynchronize());  // searches in flight on other streams still read the old storage
     if (h->xb) (void)hipFree(h->xb);
     if (h->norms) (void)hipFree(h->norms);
     h->xb = nx;
@@ -285,24 +314,12 @@ static int reserve_rows(ise_index* h, long long need, hipStream_t st) {
 static bool rows_copy_verbatim(const ise_index* h) { return h->storage == ISE_STORE_F32 && h->dp == h->d; }
 
 static bool uses_shift(const ise_index* h) { return h->storage == ISE_STORE_F32 && h->metric == ISE_METRIC_L2; }
-#define SHIFT_SAMPLE_ROWS 4096 /* the shift vector is the mean of the first rows added (at most this many) */
 
-// rows [0, n_new) have just been written at the start of an empty index: fix the shift
-static int fix_shift_from_first_rows(ise_index* h, long long n_new, hipStream_t st) {
-    if (!uses_shift(h) || h->shift_set) return ISE_OK;
-    const long long rows = std::min<long long>(n_new, SHIFT_SAMPLE_ROWS);
-    float* partial = nullptr;
-    HIP_TRY(hipMalloc(&partial, (size_t)COLMEAN_GROUPS * h->dp * sizeof(float)));
-    hipLaunchKernelGGL(col_sum_kernel, dim3((h->dp + 255) / 256, COLMEAN_GROUPS), dim3(256), 0, st,
-                       (const float*)h->xb, rows, h->d, h->dp, partial);
-    hipLaunchKernelGGL(col_mean_kernel, dim3((h->dp + 255) / 256), dim3(256), 0, st, partial, rows, h->d, h->dp, h->mu);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);  // partial is freed below
-    (void)hipFree(partial);
-    if (e != hipSuccess) return fail(ISE_E_HIP, std::string("shift vector: ") + hipGetErrorString(e));
-    h->shift_set = true;
-    return ISE_OK;
-}
+// float32 L2 indexes: bring mu and the norms up to date with the rows (called with the handle
+// locked, before a search / assignment reads them).  mu = column mean of ALL rows, recomputed when
+// the index has grown by a quarter since it was last taken (amortised O(1) per row); a new mu
+// means new norms for every row.  Rare and blocking: other streams' searches read mu and norms.
+static int prepare_shift_locked(ise_index* h, hipStream_t st);
 
 static void launch_norms(ise_index* h, long long row0, long long n, hipStream_t st) {
     const long long nblk = (n + 3) / 4;  // n < 2^32 so nblk fits the 32-bit grid
@@ -312,6 +329,43 @@ static void launch_norms(ise_index* h, long long row0, long long n, hipStream_t 
     else
         hipLaunchKernelGGL(norms_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)h->xb, row0, n, h->dp,
                            uses_shift(h) ? h->mu : (const float*)nullptr, h->norms);
+}
+
+static int prepare_shift_locked(ise_index* h, hipStream_t st) {
+    if (!uses_shift(h) || h->n == 0) return ISE_OK;
+    const bool need_mu = !h->shift_pinned && (h->mu_rows == 0 || h->n >= h->mu_rows + h->mu_rows / 4 + 1);
+    if (!need_mu && h->norms_rows == h->n) return ISE_OK;
+    HIP_TRY(hipDeviceSynchronize());  // nothing in flight reads mu / norms while they change
+    if (need_mu) {
+        const int groups = (int)std::max<long long>(1, std::min<long long>(COLMEAN_GROUPS_MAX, h->n / 64));
+        float* partial = nullptr;
+        HIP_TRY(hipMalloc(&partial, (size_t)groups * h->dp * sizeof(float)));
+        hipLaunchKernelGGL(col_sum_kernel, dim3((h->dp + 255) / 256, groups), dim3(256), 0, st, (const float*)h->xb,
+                           h->n, h->d, h->dp, groups, partial);
+        hipLaunchKernelGGL(col_mean_kernel, dim3((h->dp + 255) / 256), dim3(256), 0, st, partial, h->n, h->d, h->dp,
+                           groups, h->mu);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // partial is freed below
+        (void)hipFree(partial);
+        if (e != hipSuccess) return fail(ISE_E_HIP, std::string("shift vector: ") + hipGetErrorString(e));
+        h->mu_rows = h->n;
+        h->norms_rows = 0;
+        h->mu_updates++;
+    }
+    launch_norms(h, h->norms_rows, h->n - h->norms_rows, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    h->norms_rows = h->n;
+    return ISE_OK;
+}
+
+// n rows have just been written behind row h->n: their norms are taken now when they can be
+// (no shift, or a shift that is already fixed), otherwise with the shift at the next search
+static void norms_after_add(ise_index* h, long long n, hipStream_t st) {
+    if (uses_shift(h) && !h->shift_pinned && h->mu_rows == 0) return;
+    if (h->norms_rows != h->n) return;  // earlier rows are still waiting for the shift
+    launch_norms(h, h->n, n, st);
+    h->norms_rows = h->n + n;
 }
 
 static int add_device_locked(ise_index* h, const float* x_dev, long long n, hipStream_t st) {
@@ -331,11 +385,7 @@ static int add_device_locked(ise_index* h, const float* x_dev, long long n, hipS
             hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, st, x_dev, n, h->d, (float*)dst, h->dp);
         HIP_TRY(hipGetLastError());
     }
-    if (h->n == 0) {
-        rc = fix_shift_from_first_rows(h, n, st);
-        if (rc) return rc;
-    }
-    launch_norms(h, h->n, n, st);
+    norms_after_add(h, n, st);
     HIP_TRY(hipGetLastError());
     h->n += n;
     return ISE_OK;
@@ -345,11 +395,12 @@ extern "C" int ise_index_set_shift(ise_index_t* h, const float* mu_host) {
     if (!h || !mu_host) return fail(ISE_E_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu_);
     if (!uses_shift(h)) return ISE_OK;  // only float32 L2 indexes are shifted
-    if (h->n > 0 || h->shift_set) return fail(ISE_E_INVALID, "the shift must be set before the first add");
     DeviceGuard gd(h->device);
+    HIP_TRY(hipDeviceSynchronize());  // searches in flight read mu
     HIP_TRY(hipMemset(h->mu, 0, (size_t)h->dp * sizeof(float)));
     HIP_TRY(hipMemcpy(h->mu, mu_host, (size_t)h->d * sizeof(float), hipMemcpyHostToDevice));
-    h->shift_set = true;
+    h->shift_pinned = true;
+    h->norms_rows = 0;  // every norm is retaken around the new shift at the next search
     return ISE_OK;
 }
 
@@ -357,6 +408,8 @@ extern "C" int ise_index_get_shift(ise_index_t* h, float* mu_host) {
     if (!h || !mu_host) return fail(ISE_E_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
+    int rc = prepare_shift_locked(h, h->stream);
+    if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(mu_host, h->mu, (size_t)h->d * sizeof(float), hipMemcpyDeviceToHost));
     return ISE_OK;
@@ -390,11 +443,7 @@ extern "C" int ise_index_add_host(ise_index_t* h, const float* x, int64_t n) {
             hipError_t e = hipMemcpyAsync(dst, x + (size_t)i0 * h->d, (size_t)m * h->d * sizeof(float),
                                           hipMemcpyHostToDevice, h->stream);
             if (e != hipSuccess) return fail(ISE_E_HIP, std::string("H2D: ") + hipGetErrorString(e));
-            if (h->n == 0) {
-                rc = fix_shift_from_first_rows(h, m, h->stream);
-                if (rc) return rc;
-            }
-            launch_norms(h, h->n, m, h->stream);
+            norms_after_add(h, m, h->stream);
             h->n += m;
         } else {
             hipError_t e = hipMemcpyAsync(tmp, x + (size_t)i0 * h->d, (size_t)m * h->d * sizeof(float),
@@ -421,9 +470,9 @@ extern "C" int ise_index_add_host(ise_index_t* h, const float* x, int64_t n) {
 
 extern "C" int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n, float* out) {
     if (!h) return fail(ISE_E_INVALID, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu_);
     if (i0 < 0 || n < 0 || i0 + n > h->n || (n > 0 && !out)) return fail(ISE_E_INVALID, "row range out of bounds");
     if (n == 0) return ISE_OK;
-    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
     const char* src = static_cast<const char*>(h->xb) + (size_t)i0 * row_bytes(h);
     if (h->storage == ISE_STORE_F32) {
@@ -462,7 +511,20 @@ static void launch_scan(const ise_index* h, int ch, int waves, int T, dim3 grid,
 struct ScanPlan {
     int nblocks, tiles_total, tiles_per_block, nqt, ch, kpass, kb, waves, T;
     size_t lds;
+    bool exact;  // float32 L2: the scan is the filter of the exact search (ise_exact.hpp)
+    int kc;      // keys per query the scan + merge stage selects: k, or k + extra candidates when exact
 };
+
+// candidates kept beyond k on the exact path: enough that the certificate holds on data whose
+// neighbour spacing exceeds the bound's width (6 spare slots at k <= 10 fit the 16-slot lists)
+static int exact_extra(int k) { return k <= 10 ? 6 : (k <= 12 ? 16 - k : 4); }
+// relative width of the scan's lower bound: every rounding between the stored floats and the keyed
+// value, in units of u = 2^-24 times (|x-mu|^2 + |y-mu|^2) (derivation: DESIGN.md section 4.1)
+static float exact_beta(const ise_index* h) { return (0.5625f * h->dp + 256.f) * 5.9604645e-8f * 1.02f; }
+static bool force_exact() {  // test knob, read per call: ISE_FORCE_EXACT=1 fails every certificate (exercises the exact scan)
+    const char* e = getenv("ISE_FORCE_EXACT");
+    return e && e[0] == '1';
+}
 
 static bool xchg_enabled() {  // dev knob: ISE_NO_XCHG=1 switches the threshold exchange off
     static const bool on = [] { const char* e = getenv("ISE_NO_XCHG"); return !(e && e[0] == '1'); }();
@@ -472,7 +534,9 @@ static bool xchg_enabled() {  // dev knob: ISE_NO_XCHG=1 switches the threshold 
 // pick (query tiles per pass T, waves per block) for nq queries: the largest T <= 3
 // that the batch can use and whose LDS image fits, preferring 8 waves
 static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
-    pl->kpass = k < KPASS_MAX ? k : KPASS_MAX;
+    pl->exact = uses_shift(h);
+    pl->kc = pl->exact ? k + exact_extra(k) : k;
+    pl->kpass = pl->kc < KPASS_MAX ? pl->kc : KPASS_MAX;
     pl->kb = pl->kpass <= 16 ? 16 : 32;
     pl->ch = chunk_steps(h);
 #ifdef ISE_ABLATE
@@ -518,7 +582,8 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
             best = cost;
         }
     }
-    if (!pl->T) return fail(ISE_E_INVALID, "d too large: a 16-query tile must fit the 160 KiB LDS (d <= ~2400)");
+    if (!pl->T) return fail(ISE_E_INVALID, "d too large: a 16-query tile must fit the 160 KiB LDS "
+                                              "(float32 rows: d <= 2240, bf16 rows: d <= 4480)");
     // one query tile runs 16 waves per CU at <= 128 VGPRs: 4-step chunks (2 x 4 KB in flight per
     // wave) measured faster than 8-step ones there (no spills, more waves' worth of loads)
     if ((pl->T == 1 || pl->waves == 16) && pl->ch > 4) pl->ch = 4;  // both run at <= 128 VGPRs
@@ -547,9 +612,10 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     return ISE_OK;
 }
 
-// workspace: part [nqt][nb][16][kpass]; for k > kpass additionally
-// keys_tmp = keys_all [nq][k] | floor [nq] | pass_keys [nq][kpass]
-static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long long nq, int k) {
+// workspace of one slot: part [nqt][nb][16 T][kpass]; for kc > kpass additionally
+// keys_tmp = keys_all [nq][kc] | floor [nq] | pass_keys [nq][kpass] | exact floor [nq] | exact pass keys [nq][32];
+// exact path: the fallback list
+static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long long nq, bool* changed) {
     if (!w->done) HIP_TRY(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
     const size_t need = (size_t)pl.nqt * pl.nblocks * (16 * pl.T) * pl.kpass;
     if (need > w->part_elems) {
@@ -558,6 +624,7 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
         w->part_elems = 0;
         HIP_TRY(hipMalloc(&w->part, need * sizeof(u64)));
         w->part_elems = need;
+        *changed = true;
     }
     const size_t needx = (size_t)pl.nqt * (16 * pl.T) * pl.nblocks;
     if (needx > w->xchg_elems) {
@@ -566,22 +633,53 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
         w->xchg_elems = 0;
         HIP_TRY(hipMalloc(&w->xchg, needx * sizeof(u64)));
         HIP_TRY(hipMemset(w->xchg, 0xFF, needx * sizeof(u64)));  // tag 0xFFFFFFFF is never issued
-        HIP_TRY(hipStreamSynchronize(nullptr));  // the fill is done before any stream's launch reads it
         w->xchg_elems = needx;
         w->xchg_seq = 0;
         if (const char* e = getenv("ISE_XCHG_SEQ_START"))  // test knob: start near the tag wrap
             w->xchg_seq = (uint32_t)strtoul(e, nullptr, 0);
+        *changed = true;
     }
-    if (k > pl.kpass) {
-        const size_t need2 = (size_t)nq * ((size_t)k + 1 + pl.kpass);
+    if (pl.kc > pl.kpass) {
+        const size_t need2 = (size_t)nq * ((size_t)pl.kc + 2 + pl.kpass + KPASS_MAX);
         if (need2 > w->keys_tmp_elems) {
             if (w->keys_tmp) (void)hipFree(w->keys_tmp);
             w->keys_tmp = nullptr;
             w->keys_tmp_elems = 0;
             HIP_TRY(hipMalloc(&w->keys_tmp, need2 * sizeof(u64)));
             w->keys_tmp_elems = need2;
+            *changed = true;
         }
     }
+    if (pl.exact) {
+        if (!w->fl_state) {
+            HIP_TRY(hipMalloc(&w->fl_state, sizeof(u64)));
+            HIP_TRY(hipMemset(w->fl_state, 0, sizeof(u64)));  // tag 0 is never issued
+            w->fl_seq = 0;
+            if (const char* e = getenv("ISE_XCHG_SEQ_START")) w->fl_seq = (uint32_t)strtoul(e, nullptr, 0);
+            *changed = true;
+        }
+        if ((size_t)nq > w->fl_elems) {
+            if (w->fl_list) (void)hipFree(w->fl_list);
+            w->fl_list = nullptr;
+            w->fl_elems = 0;
+            HIP_TRY(hipMalloc(&w->fl_list, (size_t)nq * sizeof(int)));
+            w->fl_elems = (size_t)nq;
+            *changed = true;
+        }
+    }
+    return ISE_OK;
+}
+
+// Every slot is sized for the plan at once (nothing is allocated, filled or synchronised on a later
+// call of the same shape: a serving loop's steady state is allocation-free from its second batch on;
+// ise_index_reserve_workspaces does this ahead of the first batch).
+static int ensure_workspaces(ise_index* h, const ScanPlan& pl, long long nq) {
+    bool changed = false;
+    for (auto& w : h->ws) {
+        int rc = ensure_workspace(&w, pl, nq, &changed);
+        if (rc) return rc;
+    }
+    if (changed) HIP_TRY(hipDeviceSynchronize());  // the fills are done before any stream's launch reads them
     return ISE_OK;
 }
 
@@ -611,7 +709,7 @@ __global__ void decode_keys_kernel(const u64* keys, long long total, int metric,
 }
 
 struct TimedOut {
-    hipEvent_t e0, e1, e2;
+    hipEvent_t e0, e1, e2;  // scan start, scan end, end of the batch (merge / rerank / exact launches)
     bool on = false;
 };
 
@@ -624,12 +722,72 @@ static int next_xchg_seq(ise_index::WorkSlot* w, hipStream_t st, uint32_t* seq) 
     *seq = ++w->xchg_seq;
     return ISE_OK;
 }
+static int next_fl_seq(ise_index::WorkSlot* w, hipStream_t st, uint32_t* seq) {
+    if (w->fl_seq >= 0xFFFFFFF0u) {
+        HIP_TRY(hipMemsetAsync(w->fl_state, 0, sizeof(u64), st));
+        w->fl_seq = 0;
+    }
+    *seq = ++w->fl_seq;
+    return ISE_OK;
+}
 
-// enqueue one search batch; outputs (D, I) and/or keys.  Nothing here blocks.
+template <bool RERANK>
+static void launch_merge(unsigned grid, size_t lds, hipStream_t st, const MergeParams& mp, const ExactParams& xp) {
+    hipLaunchKernelGGL((merge_kernel<RERANK>), dim3(grid), dim3(MERGE_THREADS), lds, st, mp, xp);
+}
+
+// The exact fallback scan for the queries the rerank put on the slot's list: launched behind every
+// rerank and gated on the GPU (nothing is read back on the way), so a launch without failed
+// certificates costs two kernels that exit at once.  k <= 32: one exact pass written straight to
+// the outputs; larger k: one pass per 32 results, floor-keyed like the filter passes.
+static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const ScanPlan& pl, const ExactParams& xp,
+                                  long long nq, hipStream_t st) {
+    ExactScanParams xs;
+    xs.xb = (const float*)h->xb; xs.q = xp.q; xs.n = h->n; xs.d = h->d; xs.dp = h->dp;
+    xs.id_base = xp.id_base; xs.fl_state = w->fl_state; xs.fl_list = w->fl_list; xs.seq = xp.seq;
+    xs.part = w->part;  // the filter's lists are dead: [position][nblocks][kp] fits (kp <= kpass, positions <= nq)
+    xs.rows_per_block = (long long)pl.tiles_per_block * 16;
+    const size_t lds = (size_t)XQ * h->dp * 4 + (size_t)XQ * 4 * 32 * 8;
+    MergeParams mp;
+    mp.lists = w->part; mp.qt = 1; mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.metric = h->metric;
+    mp.fl_state = w->fl_state; mp.fl_list = w->fl_list; mp.seq = xp.seq;
+    const int k = xp.k;
+    if (k <= KPASS_MAX) {
+        xs.kpass = k; xs.floor_keys = nullptr;
+        hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs);
+        mp.k = k; mp.stride_list = k; mp.stride_qtile = (long long)pl.nblocks * k;
+        mp.D = xp.D; mp.I = xp.I; mp.keys_out = xp.keys_out; mp.out_by_pos = 0;
+        launch_merge<false>((unsigned)nq, 0, st, mp, xp);
+        HIP_TRY(hipGetLastError());
+        return ISE_OK;
+    }
+    u64* fb_floor = w->keys_tmp + (size_t)nq * ((size_t)pl.kc + 1 + pl.kpass);  // [nq]
+    u64* fb_pass = fb_floor + nq;                                             // [nq][KPASS_MAX]
+    const int kp = KPASS_MAX;
+    for (int off = 0; off < k; off += kp) {
+        xs.kpass = kp; xs.floor_keys = off ? fb_floor : nullptr;
+        hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs);
+        mp.k = kp; mp.stride_list = kp; mp.stride_qtile = (long long)pl.nblocks * kp;
+        mp.D = nullptr; mp.I = nullptr; mp.keys_out = fb_pass; mp.out_by_pos = 1;
+        launch_merge<false>((unsigned)nq, 0, st, mp, xp);
+        const long long tot = nq * kp;
+        hipLaunchKernelGGL(exact_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, xp,
+                           (const u64*)fb_pass, kp, off, fb_floor);
+        HIP_TRY(hipGetLastError());
+    }
+    return ISE_OK;
+}
+
+// enqueue one search batch; outputs (D, I) and/or keys.  Nothing here blocks once the slots are
+// sized (first batch of a shape) and the shift is current (first batch after rows were added).
 static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k, uint32_t id_base, float* D_dev,
                           long long* I_dev, u64* keys_out, hipStream_t st, TimedOut* tm) {
+    int rc = prepare_shift_locked(h, st);
+    if (rc) return rc;
     ScanPlan pl;
-    int rc = make_plan(h, nq, k, &pl);
+    rc = make_plan(h, nq, k, &pl);
+    if (rc) return rc;
+    rc = ensure_workspaces(h, pl, nq);
     if (rc) return rc;
     ise_index::WorkSlot* w = nullptr;
     bool same_stream = false;
@@ -639,8 +797,6 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
         for (auto& s : h->ws)
             if (!s.used) { w = &s; break; }
     if (!w) w = &h->ws[h->ws_next++ % ise_index::NWS];
-    rc = ensure_workspace(w, pl, nq, k);
-    if (rc) return rc;
     if (w->used && !same_stream) HIP_TRY(hipStreamWaitEvent(st, w->done, 0));
     struct Release {  // whatever path returns, a later user on another stream waits for this call
         ise_index::WorkSlot* w;
@@ -655,6 +811,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     sp.n = h->n; sp.d = h->d; sp.dp = h->dp; sp.qs_stride = qs_stride_for(h);
     sp.row_slots = (int)(row_bytes(h) / 16);
     sp.nq = (int)nq; sp.k = pl.kpass; sp.kb = pl.kb; sp.metric = h->metric; sp.id_base = id_base;
+    sp.beta = pl.exact ? exact_beta(h) : 0.f;
     sp.tiles_total = pl.tiles_total; sp.tiles_per_block = pl.tiles_per_block;
     sp.xchg = xchg_enabled() ? w->xchg : nullptr;
     sp.xchg_seq = 0;
@@ -670,46 +827,71 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     mp.lists = w->part; mp.stride_list = (long long)NQ * pl.kpass;
     mp.stride_qtile = (long long)pl.nblocks * NQ * pl.kpass; mp.qt = NQ;
     mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.k = pl.kpass; mp.metric = h->metric;
+    mp.fl_state = nullptr; mp.fl_list = nullptr; mp.seq = 0; mp.out_by_pos = 0;
+
+    ExactParams xp;  // used on the exact path only
+    xp.xb = (const float*)h->xb; xp.q = q_dev; xp.n = h->n; xp.d = h->d; xp.dp = h->dp; xp.nq = (int)nq;
+    xp.k = k; xp.kc = pl.kc; xp.id_base = id_base; xp.D = D_dev; xp.I = I_dev; xp.keys_out = keys_out;
+    xp.fl_state = w->fl_state; xp.fl_list = w->fl_list; xp.seq = 0; xp.stats = h->stats_dev;
+    xp.force_fail = force_exact() ? 1 : 0;
 
     const dim3 grid((unsigned)pl.nblocks, (unsigned)pl.nqt);
-    if (k <= pl.kpass) {
-        mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out;
+    if (pl.kc <= pl.kpass) {  // one scan pass selects everything the merge stage needs
         if ((rc = next_xchg_seq(w, st, &sp.xchg_seq))) return rc;
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
         launch_scan(h, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
-        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
-        HIP_TRY(hipGetLastError());
+        if (pl.exact) {  // merge the kc lower-bound keys, re-rank them exactly, certify or list for the exact scan
+            if ((rc = next_fl_seq(w, st, &xp.seq))) return rc;
+            mp.D = nullptr; mp.I = nullptr; mp.keys_out = nullptr;
+            launch_merge<true>((unsigned)nq, rerank_lds_bytes(h->dp, pl.kc), st, mp, xp);
+            HIP_TRY(hipGetLastError());
+            if ((rc = enqueue_exact_fallback(h, w, pl, xp, nq, st))) return rc;
+        } else {
+            mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out;
+            launch_merge<false>((unsigned)nq, 0, st, mp, xp);
+            HIP_TRY(hipGetLastError());
+        }
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e2, st));
         return ISE_OK;
     }
-    // k > KPASS_MAX: passes of KPASS_MAX; a pass only admits keys above the
+    // kc > KPASS_MAX: passes of KPASS_MAX; a pass only admits keys above the
     // previous pass's last key (keys are totally ordered and unique)
-    u64* keys_all = keys_out ? keys_out : w->keys_tmp;      // [nq][k]
-    u64* floor_dev = w->keys_tmp + (size_t)nq * k;          // [nq]
-    u64* pass_keys = floor_dev + nq;                        // [nq][kpass]
-    for (int off = 0; off < k; off += pl.kpass) {
+    const int kc = pl.kc;
+    u64* keys_all = (!pl.exact && keys_out) ? keys_out : w->keys_tmp;  // [nq][kc]
+    u64* floor_dev = w->keys_tmp + (size_t)nq * kc;                    // [nq]
+    u64* pass_keys = floor_dev + nq;                                   // [nq][kpass]
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
+    for (int off = 0; off < kc; off += pl.kpass) {
         sp.floor_keys = off ? floor_dev : nullptr;
         mp.D = nullptr; mp.I = nullptr; mp.keys_out = pass_keys;
         if ((rc = next_xchg_seq(w, st, &sp.xchg_seq))) return rc;
         launch_scan(h, pl.ch, pl.waves, pl.T, grid, pl.lds, st, sp);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, st, mp);
+        launch_merge<false>((unsigned)nq, 0, st, mp, xp);
         HIP_TRY(hipGetLastError());
         const int tot = (int)nq * pl.kpass;
         hipLaunchKernelGGL(scatter_pass_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, pass_keys, (int)nq,
-                           pl.kpass, keys_all, k, off);
+                           pl.kpass, keys_all, kc, off);
         hipLaunchKernelGGL(floor_from_keys_kernel, dim3(((int)nq + 255) / 256), dim3(256), 0, st, pass_keys, (int)nq,
                            pl.kpass, floor_dev);
         HIP_TRY(hipGetLastError());
     }
-    if (D_dev) {
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
+    if (pl.exact) {
+        if ((rc = next_fl_seq(w, st, &xp.seq))) return rc;
+        hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)nq), dim3(256), rerank_lds_bytes(h->dp, kc), st, xp,
+                           (const u64*)keys_all);
+        HIP_TRY(hipGetLastError());
+        if ((rc = enqueue_exact_fallback(h, w, pl, xp, nq, st))) return rc;
+    } else if (D_dev) {
         const long long total = nq * k;
         hipLaunchKernelGGL(decode_keys_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, keys_all, total,
                            h->metric, D_dev, I_dev);
         HIP_TRY(hipGetLastError());
     }
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e2, st));
     return ISE_OK;
 }
 
@@ -749,8 +931,7 @@ extern "C" int ise_index_search_timed_device(ise_index_t* h, const float* q_dev,
                                              float* merge_ms_avg) {
     int rc = check_search_args(h, q_dev, nq, k);
     if (rc) return rc;
-    if (nq == 0 || iters <= 0 || k > KPASS_MAX)
-        return fail(ISE_E_INVALID, "timed search needs nq > 0, iters > 0, k <= 32");
+    if (nq == 0 || iters <= 0) return fail(ISE_E_INVALID, "timed search needs nq > 0, iters > 0");
     if (!D_dev || !I_dev) return fail(ISE_E_INVALID, "output pointer is NULL");
     std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
@@ -781,43 +962,93 @@ extern "C" int ise_index_search_timed_device(ise_index_t* h, const float* q_dev,
     return ISE_OK;
 }
 
+// Host-API searches run on a small pool of contexts (stream + staging buffers), and hold the handle
+// lock only while their kernels are enqueued: concurrent callers (Flask request threads,
+// backend/engine.py:137; joblib threads, backend/descriptors.py:125) overlap their copies and
+// their scans instead of queueing behind one stream.
+static ise_index::HostCtx* acquire_ctx(ise_index* h) {
+    std::unique_lock<std::mutex> lk(h->hc_mu);
+    for (;;) {
+        for (auto& c : h->hc)
+            if (!c.busy) { c.busy = true; return &c; }
+        h->hc_cv.wait(lk);
+    }
+}
+static void release_ctx(ise_index* h, ise_index::HostCtx* c) {
+    { std::lock_guard<std::mutex> lk(h->hc_mu); c->busy = false; }
+    h->hc_cv.notify_one();
+}
+
 extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq, int k, float* D, int64_t* I) {
     int rc = check_search_args(h, q, nq, k);
     if (rc) return rc;
     if (nq == 0) return ISE_OK;
     if (!D || !I) return fail(ISE_E_INVALID, "output pointer is NULL");
-    std::lock_guard<std::mutex> lk(h->mu_);
     DeviceGuard gd(h->device);
+    ise_index::HostCtx* c = acquire_ctx(h);
+    struct Rel { ise_index* h; ise_index::HostCtx* c; ~Rel() { release_ctx(h, c); } } rel{h, c};
+    if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // bounds the workspace (part + multi-pass keys); larger calls loop
-    const long long batch = k <= KPASS_MAX ? 4096 : 1024;
+    const long long batch = k + 6 <= KPASS_MAX ? 4096 : 1024;
     const size_t qe = (size_t)std::min<long long>(nq, batch) * h->d;
     const size_t oe = (size_t)std::min<long long>(nq, batch) * k;
-    if (qe > h->q_elems) {
-        if (h->q_dev) (void)hipFree(h->q_dev);
-        h->q_dev = nullptr; h->q_elems = 0;
-        HIP_TRY(hipMalloc(&h->q_dev, qe * sizeof(float)));
-        h->q_elems = qe;
+    if (qe > c->q_elems) {
+        if (c->q_dev) (void)hipFree(c->q_dev);
+        c->q_dev = nullptr; c->q_elems = 0;
+        HIP_TRY(hipMalloc(&c->q_dev, qe * sizeof(float)));
+        c->q_elems = qe;
     }
-    if (oe > h->out_elems) {
-        if (h->D_dev) (void)hipFree(h->D_dev);
-        if (h->I_dev) (void)hipFree(h->I_dev);
-        h->D_dev = nullptr; h->I_dev = nullptr; h->out_elems = 0;
-        HIP_TRY(hipMalloc(&h->D_dev, oe * sizeof(float)));
-        HIP_TRY(hipMalloc(&h->I_dev, oe * sizeof(long long)));
-        h->out_elems = oe;
+    if (oe > c->out_elems) {
+        if (c->D_dev) (void)hipFree(c->D_dev);
+        if (c->I_dev) (void)hipFree(c->I_dev);
+        c->D_dev = nullptr; c->I_dev = nullptr; c->out_elems = 0;
+        HIP_TRY(hipMalloc(&c->D_dev, oe * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->I_dev, oe * sizeof(long long)));
+        c->out_elems = oe;
     }
     for (long long i0 = 0; i0 < nq; i0 += batch) {
         const long long m = std::min<long long>(batch, nq - i0);
-        HIP_TRY(hipMemcpyAsync(h->q_dev, q + (size_t)i0 * h->d, (size_t)m * h->d * sizeof(float), hipMemcpyHostToDevice,
-                               h->stream));
-        rc = search_enqueue(h, h->q_dev, m, k, 0u, h->D_dev, h->I_dev, nullptr, h->stream, nullptr);
+        HIP_TRY(hipMemcpyAsync(c->q_dev, q + (size_t)i0 * h->d, (size_t)m * h->d * sizeof(float), hipMemcpyHostToDevice,
+                               c->stream));
+        {
+            std::lock_guard<std::mutex> lk(h->mu_);
+            rc = search_enqueue(h, c->q_dev, m, k, 0u, c->D_dev, c->I_dev, nullptr, c->stream, nullptr);
+        }
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(D + (size_t)i0 * k, h->D_dev, (size_t)m * k * sizeof(float), hipMemcpyDeviceToHost,
-                               h->stream));
-        HIP_TRY(hipMemcpyAsync(I + (size_t)i0 * k, h->I_dev, (size_t)m * k * sizeof(long long), hipMemcpyDeviceToHost,
-                               h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpyAsync(D + (size_t)i0 * k, c->D_dev, (size_t)m * k * sizeof(float), hipMemcpyDeviceToHost,
+                               c->stream));
+        HIP_TRY(hipMemcpyAsync(I + (size_t)i0 * k, c->I_dev, (size_t)m * k * sizeof(long long), hipMemcpyDeviceToHost,
+                               c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return ISE_OK;
+}
+
+extern "C" int ise_index_reserve_workspaces(ise_index_t* h, int64_t nq, int k) {
+    int rc = check_search_args(h, h, nq, k);
+    if (rc) return rc;
+    if (nq == 0) return ISE_OK;
+    std::lock_guard<std::mutex> lk(h->mu_);
+    DeviceGuard gd(h->device);
+    rc = prepare_shift_locked(h, h->stream);
+    if (rc) return rc;
+    ScanPlan pl;
+    rc = make_plan(h, nq, k, &pl);
+    if (rc) return rc;
+    return ensure_workspaces(h, pl, nq);
+}
+
+extern "C" int ise_index_stats(ise_index_t* h, uint64_t* out4) {
+    if (!h || !out4) return fail(ISE_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu_);
+    DeviceGuard gd(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long tmp[4];
+    HIP_TRY(hipMemcpy(tmp, h->stats_dev, sizeof(tmp), hipMemcpyDeviceToHost));
+    out4[0] = tmp[0];
+    out4[1] = tmp[1];
+    out4[2] = h->mu_updates;
+    out4[3] = 0;
     return ISE_OK;
 }
 
@@ -856,6 +1087,10 @@ extern "C" int ise_index_assign_device(ise_index_t* h, const float* x_dev, int64
     DeviceGuard gd(h->device);
     if (!assign_supported(h))
         return fail(ISE_E_INVALID, "assignment kernel needs a non-empty float32 index with d <= 512");
+    {
+        int rc = prepare_shift_locked(h, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     AssignParams ap;
     ap.x = x_dev; ap.cb = (const float*)h->xb; ap.cnorm = h->norms; ap.mu = uses_shift(h) ? h->mu : nullptr; ap.n = n; ap.d = h->d; ap.dp = h->dp;
     ap.cs_stride = qs_stride_for(h); ap.K = (int)h->n; ap.metric = h->metric; ap.cs = assign_stage_rows(h);
@@ -900,10 +1135,11 @@ extern "C" int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int6
     mp.stride_qtile = (long long)k; mp.qt = 1;
     mp.n_lists = n_lists; mp.nq = (int)nq; mp.k = k; mp.metric = metric;
     mp.D = D_dev; mp.I = (long long*)I_dev; mp.keys_out = nullptr;
+    mp.fl_state = nullptr; mp.fl_list = nullptr; mp.seq = 0; mp.out_by_pos = 0;
     if (n_lists <= 64)
         hipLaunchKernelGGL(merge_small_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mp);
     else
-        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(MERGE_THREADS), 0, (hipStream_t)stream, mp);
+        launch_merge<false>((unsigned)nq, 0, (hipStream_t)stream, mp, ExactParams());
     HIP_TRY(hipGetLastError());
     return ISE_OK;
 }

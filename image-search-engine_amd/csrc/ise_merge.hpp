@@ -1,6 +1,7 @@
 // ise_merge.hpp -- k-way merge of sorted candidate lists.
 #pragma once
 #include "ise_common.hpp"
+#include "ise_exact.hpp"
 
 // ---------------------------------------------------------------- merge kernel
 // One block per query; thread t owns lists t, t+256, ...; k rounds of a
@@ -16,6 +17,13 @@ struct MergeParams {
     float* D;        // [nq][k] or null
     long long* I;    // [nq][k] or null
     u64* keys_out;   // [nq][k] or null
+    // gated form (the exact fallback path, ise_exact.hpp): block i serves position i of the launch's
+    // fallback list -- lists are indexed by position, results by the listed query (or by position
+    // when out_by_pos); blocks beyond the list, or of a launch without one, exit at once
+    const u64* fl_state;
+    const int* fl_list;
+    uint32_t seq;
+    int out_by_pos;
 };
 
 __device__ __forceinline__ void emit_result(const MergeParams& p, size_t o, u64 key) {
@@ -29,11 +37,22 @@ __device__ __forceinline__ void emit_result(const MergeParams& p, size_t o, u64 
     }
 }
 
-__global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams p) {
+// RERANK (float32 L2 indexes): the k = kc merged keys are lower-bound keys of the scan; they stay in
+// LDS and rerank_block (ise_exact.hpp) turns them into the exact top xp.k.
+template <bool RERANK>
+__global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams p, const ExactParams xp) {
     __shared__ u64 wmin[2][MERGE_THREADS / 64];
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    extern __shared__ __align__(16) unsigned char smem_mr[];  // RERANK only: rerank_lds_bytes(dp, kc)
+    int q = blockIdx.x, lq = blockIdx.x;
+    if (p.fl_state) {
+        const u64 st = __hip_atomic_load(p.fl_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(st >> 32) != p.seq || lq >= (int)(uint32_t)st) return;
+        q = p.out_by_pos ? lq : p.fl_list[lq];
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int k = p.k;
-    const u64* base = p.lists + (size_t)(q / p.qt) * p.stride_qtile + (size_t)(q % p.qt) * k;
+    u64* kin = RERANK ? reinterpret_cast<u64*>(smem_mr + (size_t)xp.dp * 4) : nullptr;
+    const u64* base = p.lists + (size_t)(lq / p.qt) * p.stride_qtile + (size_t)(lq % p.qt) * k;
     const u64* lst[MERGE_LPT];
     int pos[MERGE_LPT];
     u64 cur[MERGE_LPT];
@@ -55,18 +74,23 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
         for (int i = 0; i < MERGE_THREADS / 64; i++) m = min_u64(m, wmin[r & 1][i]);
         const size_t o = (size_t)q * k + r;
         if (m == KEY_PAD) {
-            if (tid == 0) emit_result(p, o, KEY_PAD);
+            if (tid == 0) {
+                if (RERANK) kin[r] = KEY_PAD;
+                else emit_result(p, o, KEY_PAD);
+            }
         } else {
             // keys are unique: exactly one list head equals m
 #pragma unroll
             for (int e = 0; e < MERGE_LPT; e++)
                 if (cur[e] == m) {
-                    emit_result(p, o, m);
+                    if (RERANK) kin[r] = m;
+                    else emit_result(p, o, m);
                     pos[e]++;
                     cur[e] = pos[e] < k ? lst[e][pos[e]] : KEY_PAD;
                 }
         }
     }
+    if (RERANK) rerank_block(xp, q, smem_mr, true, nullptr);  // starts with a block barrier
 }
 
 // Up to 64 lists (the all-gathered per-rank lists of the multi-GPU path): one wave per query,

@@ -25,31 +25,31 @@ __global__ __launch_bounds__(256) void norms_kernel(const float* __restrict__ x,
     if (lane == 0) out[r] = s;
 }
 
-// mean of the first `rows` rows per column (d columns of a padded row).  Two levels, both in a
-// fixed order (COLMEAN_GROUPS row groups summed in row order, then the groups in group order):
-// deterministic, so every index built from the same leading rows gets the same shift vector.
-#define COLMEAN_GROUPS 64
+// column mean of `rows` rows (d columns of a padded row).  Two levels, both in a fixed order
+// (`groups` row groups summed in row order, then the groups in group order): deterministic for a
+// given row count.  NaN / inf entries are skipped (they must not poison every distance).
+#define COLMEAN_GROUPS_MAX 1024
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, long long rows, int d, int dp,
-                                                      float* __restrict__ partial /* [GROUPS][dp] */) {
+                                                      int groups, float* __restrict__ partial /* [groups][dp] */) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int gidx = blockIdx.y;
     if (j >= dp) return;
-    const long long per = (rows + COLMEAN_GROUPS - 1) / COLMEAN_GROUPS;
+    const long long per = (rows + groups - 1) / groups;
     const long long r0 = gidx * per, r1 = min(rows, r0 + per);
     float s = 0.f;
     if (j < d)
         for (long long r = r0; r < r1; r++) {
             const float v = x[(size_t)r * dp + j];
-            if (fabsf(v) <= FLT_MAX) s += v;  // NaN / inf entries must not poison every distance
+            if (fabsf(v) <= FLT_MAX) s += v;
         }
     partial[(size_t)gidx * dp + j] = s;
 }
 __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ partial, long long rows, int d, int dp,
-                                                       float* __restrict__ mu) {
+                                                       int groups, float* __restrict__ mu) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= dp) return;
     float s = 0.f;
-    for (int gi = 0; gi < COLMEAN_GROUPS; gi++) s += partial[(size_t)gi * dp + j];
+    for (int gi = 0; gi < groups; gi++) s += partial[(size_t)gi * dp + j];
     const float m = s / (float)rows;
     mu[j] = (j < d && fabsf(m) <= FLT_MAX) ? m : 0.f;
 }

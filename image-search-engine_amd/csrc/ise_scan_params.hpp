@@ -18,6 +18,7 @@ struct ScanParams {
     int row_slots;         // 16-byte slots per index row = dp * elem_size / 16; one k-step = 4 slots
     int nq, k, kb, metric;  // kb: block-list slots per query (16 or 32, >= k)
     uint32_t id_base;
+    float beta;  // SHIFT kernels: relative width of the lower bound the rows are keyed by (0 = none)
     int tiles_total, tiles_per_block;
     // one-shot threshold exchange: [nqt][16 T][nblocks] entries (launch seq << 32 | ord(score) of the
     // block's best boot row); null = off.  See scan_kernel.
@@ -27,7 +28,6 @@ struct ScanParams {
     unsigned long long* stamps;  // dev builds: [blocks][waves][16] stamps (0-7 s_memrealtime 100 MHz, 8-9 s_memtime), or null
 };
 
-#define TAU0 ((u64)0xFF7FFFFFu << 32) /* ord(FLT_MAX) << 32: strict gate score < FLT_MAX */
 #define CAP 16       /* slots of a wave's private candidate list; folded out at MERGE_TRIG */
 #define MERGE_TRIG 12
 #define KB_MAX 32    /* block-list slots per query (runtime kb = 16 or 32), >= k of one pass */

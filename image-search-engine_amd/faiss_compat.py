@@ -91,8 +91,21 @@ class IndexFlat:
     def reset(self) -> None:
         _n.check(_n.lib.ise_index_reset(self._h))
 
-    # float32 L2 indexes evaluate distances around a fixed shift vector (see include/ise_knn.h);
-    # shards of one logical index share it
+    def exact_stats(self) -> dict:
+        """Counters of the exact float32 L2 path (include/ise_knn.h, ise_index_stats): queries
+        re-ranked, queries the certificate sent to the exact direct-difference scan, refreshes of the
+        shift vector."""
+        out = (ctypes.c_uint64 * 4)()
+        _n.check(_n.lib.ise_index_stats(self._h, out))
+        return {"reranked": int(out[0]), "exact_scan": int(out[1]), "shift_updates": int(out[2])}
+
+    def reserve(self, nq: int, k: int) -> None:
+        """Size every internal workspace for batches of ``nq`` queries / ``k`` results now, so that the
+        first search of that shape allocates nothing (serving loops, bench.py)."""
+        _n.check(_n.lib.ise_index_reserve_workspaces(self._h, int(nq), int(k)))
+
+    # float32 L2 indexes filter around a shift vector (see include/ise_knn.h); results do not depend
+    # on it
     def get_shift(self) -> np.ndarray:
         mu = np.zeros(self.d, dtype=np.float32)
         _n.check(_n.lib.ise_index_get_shift(self._h, mu.ctypes.data))

@@ -44,13 +44,6 @@ class HipShardBackend:
         else:
             self.index.add(x.numpy() if isinstance(x, torch.Tensor) else x)
 
-    # the L2 shift vector (include/ise_knn.h): shard 0 defines it, the others adopt it
-    def get_shift(self) -> torch.Tensor:
-        return torch.from_numpy(self.index.get_shift())
-
-    def set_shift(self, mu: torch.Tensor) -> None:
-        self.index.set_shift(mu.cpu().numpy())
-
     def local_search_keys(self, xq: torch.Tensor, k: int, id_base: int) -> torch.Tensor:
         return self.index.search_keys_torch(xq, k, id_base)
 
@@ -102,19 +95,9 @@ class ShardedIndexFlat:
         if self.ntotal:
             raise RuntimeError("sharded index is append-once: ids must stay contiguous per rank")
         dev = getattr(self.backend, "device", torch.device("cpu"))
-        if hasattr(self.backend, "get_shift"):
-            # every shard must measure distances around the same shift vector as an unsharded
-            # index would: rank 0 (which holds the first rows) fixes it by adding first
-            mu = torch.zeros(self.d, dtype=torch.float32, device=dev)
-            if self.rank == 0:
-                self.backend.add(x_local)
-                mu.copy_(self.backend.get_shift())
-            dist.broadcast(mu, src=0, group=self.group)
-            if self.rank != 0:
-                self.backend.set_shift(mu)
-                self.backend.add(x_local)
-        else:
-            self.backend.add(x_local)
+        # no exchange on the build side: every shard's search is exact on its own (float32 L2 shards
+        # re-rank by the direct difference, csrc/ise_exact.hpp), so shards share nothing but the id space
+        self.backend.add(x_local)
         mine = torch.tensor([x_local.shape[0]], dtype=torch.int64, device=dev)
         allc = torch.empty(self.world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allc, mine, group=self.group)
@@ -223,6 +206,9 @@ class SearchPipeline:
                 b["ready"].record(torch.cuda.current_stream(self.dev))
                 b["stream"].wait_event(b["ready"])
             be.local_search_keys_into(xq, self.k, self.index.id_base, b["keys_g"][g], b["handle"])
+            # the scan reads xq on the bucket's stream: the caching allocator must not hand xq's memory
+            # to a later allocation on the caller's stream while that read is pending
+            xq.record_stream(b["stream"])
         elif self.into:
             be.local_search_keys_into(xq, self.k, self.index.id_base, b["keys_g"][g])
         else:

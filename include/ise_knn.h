@@ -22,7 +22,8 @@
  *     unfilled slots come back as id -1 / distance +-FLT_MAX.
  *   - ids are row numbers in insertion order (+ id_base); a (sharded) index
  *     holds fewer than 2^32 rows.
- *   - concurrent *_host calls on one handle are safe (serialised per handle);
+ *   - concurrent *_host calls on one handle are safe and overlap on the GPU (each runs on one of
+ *     a few internal contexts; the handle is locked only while kernels are enqueued);
  *     *_device calls on one handle may target different streams (the handle
  *     rotates through a few workspaces and orders their reuse with events, so
  *     independent batches on different streams overlap on the GPU); results of
@@ -75,13 +76,28 @@ int ise_index_info(const ise_index_t* h, int* d, int* metric, int64_t* ntotal, i
 int ise_index_add_host(ise_index_t* h, const float* x, int64_t n);
 int ise_index_add_device(ise_index_t* h, const float* x_dev, int64_t n, void* stream);
 
-/* Float32 L2 indexes evaluate distances around a fixed shift vector mu (distances are
- * translation invariant; see csrc/ise_knn.hip, SHIFT).  By default mu is the mean of
- * the first rows added.  Shards of one logical index must share it: read it from the
- * shard that holds the first rows and set it on the others BEFORE their first add.
- * mu: d float32 on the host.  No-ops for inner-product and bf16 indexes. */
+/* Float32 L2 indexes are searched EXACTLY: the streaming scan evaluates the expanded form
+ * |x-mu|^2 + |y-mu|^2 - 2 (x-mu).(y-mu) around a shift vector mu (the column mean of the rows,
+ * refreshed at the first search after the index has grown by a quarter) only as a filter keyed by
+ * a rigorous lower bound; the candidates are re-evaluated as sum (x_i - y_i)^2 -- what Faiss's
+ * IndexFlatL2 computes for the reference's one-query searches (backend/engine.py:55) -- and a
+ * query the filter cannot certify is recomputed by a direct-difference scan of the whole index
+ * (csrc/ise_exact.hpp).  Ids and distances therefore do not depend on mu; it only decides how
+ * often the slower path runs.  set_shift pins mu (no automatic refresh) -- e.g. to give the shards
+ * of one logical index the same one; get_shift returns the current one.  mu: d float32 on the
+ * host.  No-ops for inner-product and bf16 indexes. */
 int ise_index_set_shift(ise_index_t* h, const float* mu_host);
 int ise_index_get_shift(ise_index_t* h, float* mu_host);
+
+/* Counters of the exact float32 L2 path since the index was created:
+ *   out4[0] queries re-ranked, out4[1] queries whose certificate failed and that were recomputed by
+ *   the exact scan, out4[2] refreshes of the shift vector, out4[3] reserved (0).  Blocks. */
+int ise_index_stats(ise_index_t* h, uint64_t* out4);
+
+/* Size every internal workspace for batches of nq queries and k results now (device allocations,
+ * fills and the shift refresh otherwise happen inside the first search of that shape), so that a
+ * serving loop is allocation-free from its first batch on.  Blocks. */
+int ise_index_reserve_workspaces(ise_index_t* h, int64_t nq, int k);
 
 /* copy rows [i0, i0+n) back to host as n x d float32 (used by write_index,
  * backend/indexer.py:59). */
@@ -135,11 +151,11 @@ int ise_normalize_rows_host(float* x, int64_t n, int d, int device);
 int ise_bovw_histogram_device(const int64_t* labels_dev, const int64_t* offsets_dev,
                               int64_t n_images, int K, double* out_dev, int device, void* stream);
 
-/* measurement hook for bench.py: run the scan + merge kernels of one search
- * batch `iters` times on `stream` and return the average scan-kernel and
- * merge-kernel durations in milliseconds, measured with hipEvents recorded on
- * that stream around each kernel.  Results land in D_dev / I_dev as for
- * ise_index_search_device. */
+/* measurement hook for bench.py: run one search batch `iters` times on `stream` and return
+ * the average duration of the scan kernel (all filter passes when k needs several) and of
+ * everything behind it (merge + exact re-rank + the gated exact-scan launches) in milliseconds,
+ * measured with hipEvents recorded on that stream around the kernels.  Results land in
+ * D_dev / I_dev as for ise_index_search_device. */
 int ise_index_search_timed_device(ise_index_t* h, const float* q_dev, int64_t nq, int k,
                                   float* D_dev, int64_t* I_dev, void* stream, int iters,
                                   float* scan_ms_avg, float* merge_ms_avg);

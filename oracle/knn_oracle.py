@@ -123,9 +123,18 @@ def _pairwise_blocked(xq, xb, metric):
     q = xq.astype(np.float64)
     out = np.empty((q.shape[0], xb.shape[0]), dtype=np.float64)
     step = 1 << 17
+    # L2 is translation invariant: taking it around the column mean keeps the expanded form's
+    # float64 error (~1e-16 of the squared norms) far below float32 resolution of the distances even
+    # when the rows sit far from the origin or in far-apart clusters
+    centre = np.zeros(q.shape[1])
+    if metric != METRIC_INNER_PRODUCT:
+        for s in range(0, xb.shape[0], step):
+            centre += xb[s : s + step].astype(np.float64).sum(0)
+        centre /= xb.shape[0]
+        q = q - centre
     qn = np.einsum("ij,ij->i", q, q)
     for s in range(0, xb.shape[0], step):
-        b = xb[s : s + step].astype(np.float64)
+        b = xb[s : s + step].astype(np.float64) - centre
         ip = q @ b.T
         if metric == METRIC_INNER_PRODUCT:
             out[:, s : s + step] = ip

@@ -1,0 +1,317 @@
+"""GPU parity tests of the EXACT float32 L2 search (csrc/ise_exact.hpp): the streaming scan is a
+filter keyed by a rigorous lower bound, candidates are re-ranked by the direct difference
+sum (x - y)^2 -- what Faiss's IndexFlatL2 computes for the reference's one-query searches
+(backend/engine.py:50-55; numpy restatement backend/siamese/test_index.py:58-69) -- and queries the
+filter cannot certify go to an exact direct-difference scan.  The data here is built to break an
+expanded-form kernel: means that drift, far-apart clusters, outliers, massive duplicates.
+Expected values: the float64 oracle (parity unpinned w.r.t. a real Faiss build, see oracle/)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import knn_oracle as ko
+from tests.knn_checks import ATOL_UNIFORM, assert_knn_matches
+
+pytestmark = pytest.mark.gpu
+L2 = ko.METRIC_L2
+
+
+@pytest.fixture(scope="module")
+def faiss():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import image_search_engine_amd.faiss_compat as fc
+
+    return fc
+
+
+class forced_exact:
+    """Every certificate fails inside the block: the exact fallback scan produces the results."""
+
+    def __enter__(self):
+        os.environ["ISE_FORCE_EXACT"] = "1"
+
+    def __exit__(self, *a):
+        os.environ.pop("ISE_FORCE_EXACT", None)
+
+
+def _adversarial(kind, rng, n, d):
+    if kind == "cluster_sorted":      # rows sorted by class: the mean drifts all the way through the index
+        c = np.sort(rng.integers(0, 8, n))
+        centres = (rng.standard_normal((8, d)) * 20.0).astype(np.float32)
+        xb = centres[c] + 0.1 * rng.standard_normal((n, d)).astype(np.float32)
+    elif kind == "two_far_clusters":  # 1e3 apart, spread 1e-1: |y - mu|^2 ~ 2.5e5 against neighbour gaps ~ 1e-2
+        off = np.zeros(d, np.float32)
+        off[0] = 1000.0
+        xb = 0.1 * rng.standard_normal((n, d)).astype(np.float32)
+        xb[n // 2:] += off
+    elif kind == "outlier_first":     # the first row is nothing like the rest
+        xb = (5.0 + 0.05 * rng.standard_normal((n, d))).astype(np.float32)
+        xb[0] = 1e3
+    elif kind == "huge_norm_rows":    # a few rows with 1e4 times the norm of the rest
+        xb = rng.random((n, d), dtype=np.float32)
+        xb[rng.integers(0, n, 5)] *= 1e4
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(xb, dtype=np.float32)
+
+
+@pytest.mark.parametrize("adds", ["one", "several"])
+@pytest.mark.parametrize("nq", [1, 16])
+@pytest.mark.parametrize("kind", ["cluster_sorted", "two_far_clusters", "outlier_first", "huge_norm_rows"])
+def test_l2_exact_on_adversarial_data(faiss, kind, nq, adds):
+    rng = np.random.default_rng(zlib.crc32(f"{kind}{nq}".encode()))
+    n, d, k = 24_000, 128, 10
+    xb = _adversarial(kind, rng, n, d)
+    xq = (xb[rng.integers(0, n, nq)] + 0.03 * rng.standard_normal((nq, d))).astype(np.float32)
+    index = faiss.IndexFlatL2(d)
+    if adds == "one":
+        index.add(xb)
+    else:  # a one-row first add, then uneven pieces with a search in between (the shift is refreshed lazily)
+        index.add(xb[:1])
+        index.add(xb[1:5000])
+        index.search(xq, k)
+        index.add(xb[5000:5003])
+        index.add(xb[5003:])
+    D, I = index.search(xq, k)
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
+    n_mism = assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2, gap=ko.kth_gap(xb, xq, k, L2))
+    assert n_mism == 0 or kind == "two_far_clusters"  # only float32 near-ties may differ, and only there
+    st = index.exact_stats()
+    assert st["reranked"] >= nq
+    if kind == "two_far_clusters":
+        assert st["exact_scan"] > 0, "the filter cannot certify this data: the exact scan must have run"
+
+
+def test_certificate_holds_on_benign_data_and_forced_exact_agrees(faiss):
+    """uniform[0,1) (the benchmark distribution): no query needs the exact scan; forcing it returns
+    the same bits (both paths evaluate the same d(x, y)); distances within the ABSOLUTE 1e-4."""
+    rng = np.random.default_rng(5)
+    n, d = 50_000, 512
+    xb = rng.random((n, d), dtype=np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    for nq, k in ((1, 10), (16, 10), (40, 20), (5, 1), (7, 32), (3, 33), (4, 100)):
+        xq = rng.random((nq, d), dtype=np.float32)
+        before = index.exact_stats()
+        D, I = index.search(xq, k)
+        after = index.exact_stats()
+        assert after["reranked"] - before["reranked"] == nq
+        assert after["exact_scan"] == before["exact_scan"], "certificate failed on uniform data"
+        D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
+        assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2, gap=ko.kth_gap(xb, xq, k, L2), atol=ATOL_UNIFORM)
+        with forced_exact():
+            Df, If = index.search(xq, k)
+        assert index.exact_stats()["exact_scan"] - after["exact_scan"] == nq
+        assert np.array_equal(If, I) and np.array_equal(Df, D)
+
+
+def test_massive_duplicates_go_through_the_exact_scan(faiss):
+    """More copies of the nearest row than candidate slots: the filter cannot separate them from the
+    rest, the exact scan returns the lowest ids (Faiss tie order)."""
+    rng = np.random.default_rng(8)
+    n, d, k = 6000, 64, 10
+    xb = rng.random((n, d), dtype=np.float32)
+    dup = np.sort(rng.choice(n, 200, replace=False))
+    xb[dup] = xb[dup[0]]
+    xq = np.stack([xb[dup[0]], xb[dup[0]] + np.float32(0.001)]).astype(np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    assert np.array_equal(I[0], dup[:k]) and (D[0] == 0).all()
+    assert np.array_equal(I[1], dup[:k])
+    assert index.exact_stats()["exact_scan"] == 2
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2)
+
+
+def test_exact_keys_shards_merge_to_the_unsharded_result(faiss):
+    """Shards need not share anything: each re-ranks exactly on its own, the packed keys carry the
+    direct-difference distance, and the merge equals one index -- also through the exact scan."""
+    import torch
+
+    rng = np.random.default_rng(12)
+    n, d, k = 30_000, 96, 10
+    xb = _adversarial("cluster_sorted", rng, n, d)
+    xq = (xb[rng.integers(0, n, 20)] + 0.02 * rng.standard_normal((20, d))).astype(np.float32)
+    tq = torch.from_numpy(xq).cuda()
+    whole = faiss.IndexFlatL2(d)
+    whole.add(xb)
+    D0, I0 = whole.search(xq, k)
+    for force in (False, True):
+        keys = []
+        for r in range(3):
+            lo, hi = n * r // 3, n * (r + 1) // 3
+            sh = faiss.IndexFlatL2(d)
+            sh.add(xb[lo:hi])
+            if force:
+                with forced_exact():
+                    keys.append(sh.search_keys_torch(tq, k, id_base=lo))
+                    torch.cuda.synchronize()
+            else:
+                keys.append(sh.search_keys_torch(tq, k, id_base=lo))
+        D1, I1 = faiss.merge_keys_torch(torch.stack(keys), L2)
+        assert np.array_equal(I0, I1.cpu().numpy()) and np.array_equal(D0, D1.cpu().numpy())
+
+
+def test_pinned_shift_changes_nothing_but_the_path(faiss):
+    """Results do not depend on the shift vector: a deliberately bad one only sends queries to the
+    exact scan."""
+    rng = np.random.default_rng(3)
+    n, d, k = 20_000, 128, 10
+    xb = (3.0 + 0.2 * rng.standard_normal((n, d))).astype(np.float32)
+    xq = (3.0 + 0.2 * rng.standard_normal((8, d))).astype(np.float32)
+    good = faiss.IndexFlatL2(d)
+    good.add(xb)
+    D0, I0 = good.search(xq, k)
+    bad = faiss.IndexFlatL2(d)
+    bad.set_shift(np.full(d, -3000.0, np.float32))
+    bad.add(xb)
+    D1, I1 = bad.search(xq, k)
+    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+    assert np.allclose(bad.get_shift(), -3000.0)
+    assert good.exact_stats()["exact_scan"] == 0 and bad.exact_stats()["exact_scan"] > 0
+    assert abs(float(good.get_shift().mean()) - 3.0) < 0.01
+
+
+def test_shift_is_refreshed_as_the_index_grows(faiss):
+    rng = np.random.default_rng(4)
+    d = 64
+    index = faiss.IndexFlatL2(d)
+    index.add(np.full((1, d), 100.0, np.float32))      # an outlier first add
+    xq = rng.random((2, d), dtype=np.float32)
+    index.search(xq, 1)
+    assert index.exact_stats()["shift_updates"] == 1 and np.allclose(index.get_shift(), 100.0)
+    rows = rng.random((4000, d), dtype=np.float32)
+    index.add(rows)
+    D, I = index.search(xq, 5)
+    assert index.exact_stats()["shift_updates"] == 2
+    assert abs(float(index.get_shift().mean()) - (0.5 * 4000 + 100.0) / 4001) < 0.01
+    index.add(rows[:100])                               # < a quarter more rows: the shift stays
+    index.search(xq, 5)
+    assert index.exact_stats()["shift_updates"] == 2
+    xb = np.concatenate([np.full((1, d), 100.0, np.float32), rows, rows[:100]])
+    D, I = index.search(xq, 5)
+    D_ref, I_ref = ko.knn_exact(xb, xq, 5, L2)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2)
+
+
+def test_reserve_workspaces_then_search_allocates_nothing_new(faiss):
+    """ise_index_reserve_workspaces: sizes every slot ahead of the first batch (bench.py calls it
+    before its warm-up); searches on many streams afterwards agree with the oracle."""
+    import torch
+
+    rng = np.random.default_rng(6)
+    n, d, k, nq = 40_000, 128, 10, 16
+    xb = rng.random((n, d), dtype=np.float32)
+    xq = rng.random((nq, d), dtype=np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    index.reserve(nq, k)
+    free0 = torch.cuda.mem_get_info()[0]
+    tq = torch.from_numpy(xq).cuda()
+    streams = [torch.cuda.Stream() for _ in range(16)]
+    outs = [(torch.empty((nq, k), dtype=torch.float32, device="cuda"),
+             torch.empty((nq, k), dtype=torch.int64, device="cuda")) for _ in streams]
+    for s, (D, I) in zip(streams, outs):  # first use of a stream creates its hardware queue (runtime memory)
+        with torch.cuda.stream(s):
+            D.zero_()
+    index.search_into(tq, k, outs[0][0], outs[0][1], streams[0].cuda_stream)  # loads the code objects
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):  # 16 streams over the library's six slots: every slot gets used
+        for s, (D, I) in zip(streams, outs):
+            index.search_into(tq, k, D, I, s.cuda_stream)
+    torch.cuda.synchronize()
+    # one slot's candidate lists alone are 1 MiB here: a lazily sized slot would show
+    assert torch.cuda.mem_get_info()[0] >= free1 - (1 << 19), "a search allocated device memory after reserve()"
+    del free0
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
+    for D, I in outs:
+        assert_knn_matches(D.cpu().numpy(), I.cpu().numpy(), D_ref, I_ref, xb, xq, L2, atol=ATOL_UNIFORM)
+
+
+# ---------------------------------------------------------------- kernel instantiations round 1 never ran
+@pytest.mark.parametrize("metric", [ko.METRIC_INNER_PRODUCT, L2])
+@pytest.mark.parametrize("nq", [49, 64, 100])
+def test_bf16_four_query_tiles(faiss, metric, nq):
+    """scan_kernel<*, 8, 4, bf16>: chosen for nq >= 49 on bf16 rows (BASELINE config 5's large batches)."""
+    import torch
+
+    rng = np.random.default_rng(nq + metric)
+    n, d, k = 30_000, 512, 10
+    xb = rng.standard_normal((n, d)).astype(np.float32)
+    xq = rng.standard_normal((nq, d)).astype(np.float32)
+    rb = torch.from_numpy(xb).to(torch.bfloat16).to(torch.float32).numpy()
+    rq = torch.from_numpy(xq).to(torch.bfloat16).to(torch.float32).numpy()
+    index = faiss.IndexFlat(d, metric, storage="bf16")
+    index.add(xb)
+    D, I = index.search(xq, k)
+    D_ref, I_ref = ko.knn_exact(rb, rq, k, metric)
+    assert_knn_matches(D, I, D_ref, I_ref, rb, rq, metric, gap=ko.kth_gap(rb, rq, k, metric))
+
+
+@pytest.mark.parametrize("storage,d", [("f32", 2100), ("f32", 2176), ("f32", 2240),
+                                       ("bf16", 2304), ("bf16", 4400), ("bf16", 4480)])
+def test_long_rows_four_wave_blocks(faiss, storage, d):
+    """Rows of more than 8448 bytes (float32: 2112 < d <= 2240, bf16: 4224 < d <= 4480): 8 waves'
+    candidate lists no longer fit beside a 16-query tile in the 160 KiB LDS, the host picks 4-wave
+    blocks (scan_kernel<*, 4, 1, ...>); the shorter rows here are the longest the 8-wave kernel takes."""
+    import torch
+
+    rng = np.random.default_rng(d)
+    n, nq, k = 2000, 5, 10
+    xb = rng.random((n, d), dtype=np.float32)
+    xq = rng.random((nq, d), dtype=np.float32)
+    for metric in (L2, ko.METRIC_INNER_PRODUCT):
+        index = faiss.IndexFlat(d, metric, storage=storage)
+        index.add(xb)
+        D, I = index.search(xq, k)
+        if storage == "bf16":
+            rb = torch.from_numpy(xb).to(torch.bfloat16).to(torch.float32).numpy()
+            rq = torch.from_numpy(xq).to(torch.bfloat16).to(torch.float32).numpy()
+        else:
+            rb, rq = xb, xq
+        D_ref, I_ref = ko.knn_exact(rb, rq, k, metric)
+        assert_knn_matches(D, I, D_ref, I_ref, rb, rq, metric, gap=ko.kth_gap(rb, rq, k, metric))
+
+
+def test_d_too_large_is_an_error_not_a_wrong_answer(faiss):
+    from image_search_engine_amd._native import IseError
+
+    for d, storage in ((2241, "f32"), (2304, "f32"), (4481, "bf16")):
+        index = faiss.IndexFlat(d, L2, storage=storage)
+        index.add(np.zeros((32, d), np.float32))
+        with pytest.raises(IseError, match="d too large"):
+            index.search(np.zeros((1, d), np.float32), 3)
+
+
+def test_concurrent_host_searches_overlap_and_agree(faiss):
+    """Flask request threads (backend/engine.py:137): the host API serves concurrent callers from a
+    pool of contexts; every caller gets its own correct answer."""
+    import threading
+
+    rng = np.random.default_rng(10)
+    n, d, k = 60_000, 128, 20
+    xb = rng.random((n, d), dtype=np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    qs = [rng.random((1 + i % 3, d), dtype=np.float32) for i in range(12)]
+    refs = [ko.knn_exact(xb, q, k, L2) for q in qs]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(10):
+                D, I = index.search(qs[i], k)
+                assert_knn_matches(D, I, refs[i][0], refs[i][1], xb, qs[i], L2, atol=ATOL_UNIFORM)
+        except Exception as e:
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(qs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors

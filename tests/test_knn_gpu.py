@@ -262,7 +262,6 @@ def test_shard_keys_merge_equals_unsharded(faiss):
         for r in range(G):
             lo, hi = 12345 * r // G, 12345 * (r + 1) // G
             sh = make_index(faiss, metric, 96)
-            sh.set_shift(whole.get_shift())  # shards share the unsharded index's shift vector
             sh.add(xb[lo:hi])
             keys.append(sh.search_keys_torch(tq, 10, id_base=lo))
         D1, I1 = faiss.merge_keys_torch(torch.stack(keys), metric)
@@ -307,7 +306,6 @@ def test_full_size_properties(faiss):
     # two shards + merge
     half = n // 2
     a, b = faiss.IndexFlatL2(d), faiss.IndexFlatL2(d)
-    b.set_shift(index.get_shift())  # a fixes the same shift itself: it holds the first rows
     a.add_torch(xb[:half])
     b.add_torch(xb[half:])
     keys = torch.stack([a.search_keys_torch(xq, k, 0), b.search_keys_torch(xq, k, half)])
@@ -517,7 +515,6 @@ def test_shards_with_three_query_tiles_equal_unsharded(faiss):
         for r in range(G):
             lo, hi = n * r // G, n * (r + 1) // G
             sh = make_index(faiss, metric, d)
-            sh.set_shift(whole.get_shift())
             sh.add(xb[lo:hi])
             keys.append(sh.search_keys_torch(tq, k, id_base=lo))
         D1, I1 = faiss.merge_keys_torch(torch.stack(keys), metric)
