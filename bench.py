@@ -54,6 +54,7 @@ def host_cores():
 
 
 PROFILE_ROUND = "r02"
+CLOCK_WARMUP_STEPS = 400  # untimed, before the W warm-up steps: see main()
 
 
 def kernel_source_hash():
@@ -232,6 +233,13 @@ def main():
     # short the warm-up is
     local.reserve(nq, k)
     torch.cuda.synchronize()
+    # The GPU leaves its idle power state over the first tens of milliseconds of work (measured,
+    # scripts/short_run_probe.py: the same 20 steps take 400 us each right after the index build, 315
+    # after 30 ms of searches, 380 again after half a second of idling).  A server is never idle, so
+    # the clocks are brought up with untimed steps of the same kind before the W warm-up steps; the
+    # timed region itself is untouched (exactly K steps, nothing skipped).
+    run(CLOCK_WARMUP_STEPS)
+    torch.cuda.synchronize()
     run(max(1, args.warmup))
     torch.cuda.synchronize()
     barrier()
@@ -287,7 +295,9 @@ def main():
                                    f"nq={nq} queries per step, index resident in HBM, "
                                    + (f"row-sharded over {world} GPUs, one all-gather + merge per {depth} steps, "
                                       f"4 buckets (streams) in flight" if sharded else
-                                      f"steps issued round-robin on {n_streams} HIP streams"),
+                                      f"steps issued round-robin on {n_streams} HIP streams")
+                                   + f"; {CLOCK_WARMUP_STEPS} untimed steps ahead of the warm-up bring the GPU out of "
+                                     f"its idle power state",
                        "n": n, "d": d, "k": k, "nq": nq},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, d, nq, k, world),

@@ -26,7 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from .config import Config, DnnModels
-from .resnet import fold_batchnorm_, resnet50_features
+from .resnet import fold_batchnorm_, load_resnet50_weights, resnet50_features
 from .utils import chunkIt
 
 config = Config()
@@ -49,8 +49,14 @@ class CNNDescriptor:
     """
 
     def __init__(self, model=DnnModels.RESNET, seed: int = 0, out_dim: int | None = None,
-                 device: str | None = None, dtype: torch.dtype = torch.float32, fold_bn: bool = True):
+                 device: str | None = None, dtype: torch.dtype = torch.float32, fold_bn: bool = True,
+                 weights_path=None):
+        """``weights_path``: a torchvision ResNet-50 ``state_dict`` file (e.g. IMAGENET1K_V2, what the
+        reference downloads at backend/descriptors.py:161-163) loaded with ``weights_only=True``
+        before BatchNorm is folded; ``fc.*`` entries are ignored.  None = seeded random init
+        (BASELINE config 2; there is no network here)."""
         self.model = model
+        self.weights_path = weights_path
         self.seed = seed
         self.out_dim = out_dim
         self.device = torch.device(device or config.DEVICE)
@@ -65,6 +71,8 @@ class CNNDescriptor:
         if self.model == DnnModels.RESNET:
             self.preprocessor = self._preprocess_batch
             net = resnet50_features(self.seed)
+            if self.weights_path is not None:
+                load_resnet50_weights(net, self.weights_path)
             if self.fold_bn:
                 net = fold_batchnorm_(net)
             self.feature_extractor = net.to(self.device).to(memory_format=torch.channels_last)
@@ -140,6 +148,15 @@ class CNNDescriptor:
     extract = describe  # name used by BASELINE.json's north_star
 
 
+class Descriptions(defaultdict):
+    """What ``Describer.describe`` returns: the reference's ``{name: [per-image arrays]}`` dict
+    (backend/descriptors.py:77,99-101) plus, beside it, the path each array came from."""
+
+    def __init__(self):
+        super().__init__(list)
+        self.paths = defaultdict(list)
+
+
 class Describer:
     """backend/descriptors.py:47-101.  Descriptors exposing ``describe_batch`` are fed
     ``batch_size`` images per call; results and skip-on-error behaviour are unchanged."""
@@ -147,6 +164,10 @@ class Describer:
     def __init__(self, descriptors: dict[str, SupportsDescribe], batch_size: int | None = None):
         self.descriptors = self._validate_descriptors(descriptors)
         self.batch_size = batch_size or config.DNN_BATCH_SIZE
+        # paths whose description made it into the last describe_dataset() result, in result order:
+        # row i of the index built from that result is described_paths[i] (the reference loses this
+        # when an image is skipped)
+        self.described_paths: list = []
 
     def _validate_descriptors(self, descriptors):
         if not descriptors:
@@ -174,6 +195,7 @@ class Describer:
                     feats = descriptor.describe_batch(list(images))
                     for f in feats:
                         descriptions[d_name].append(f.reshape(1, -1))
+                    descriptions.paths[d_name].extend(paths)
                     continue
                 except Exception as e:  # fall back to per-image so one bad image skips alone
                     print(f"ERROR: batched describe failed ({e}); retrying per image")
@@ -185,6 +207,7 @@ class Describer:
                     if description.ndim == 1:
                         description = description.reshape(1, -1)
                     descriptions[d_name].append(description)
+                    descriptions.paths[d_name].append(img_path)
                 except Exception as e:
                     print(f"ERROR: Problem describing image '{img_path}'\n '{e}'")
         pending.clear()
@@ -201,7 +224,7 @@ class Describer:
         order and skip-on-error behaviour are those of the reference's sequential loop."""
         from concurrent.futures import ThreadPoolExecutor
 
-        descriptions: dict[str, list] = defaultdict(list)
+        descriptions = Descriptions()
         pending = []
         paths = np.asarray(images_paths).ravel().tolist()
         workers = max(1, int(getattr(config, "DECODE_WORKERS", 8)))
@@ -244,8 +267,11 @@ def describe_dataset(describer: Describer, images_paths: np.ndarray, prediction=
     with Parallel(backend="threading", n_jobs=n_jobs) as parallel:
         dicts = parallel(delayed(describer.describe)(paths, n_jobs > 1) for paths in paths_chunks)
     descriptions = []
+    described = []
     for descriptions_dict in dicts:
         for key in descriptions_dict.keys():
             for image_description in descriptions_dict[key]:
                 descriptions.append(image_description)
+            described.extend(getattr(descriptions_dict, "paths", {}).get(key, []))
+    describer.described_paths = described
     return descriptions

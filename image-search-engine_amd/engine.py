@@ -21,11 +21,36 @@ images_paths = None
 descriptor = None
 
 
+def paths_file_for(index_path):
+    """The row-id -> image-path list that ``indexer.main`` writes beside the index file."""
+    from pathlib import Path
+
+    p = Path(str(index_path))
+    return p.with_name(p.name + ".paths.json")
+
+
 def load(index_path=None, paths=None, desc=None):
-    """Bind the module globals (backend/engine.py:110-117 for METHOD=DNN)."""
+    """Bind the module globals (backend/engine.py:110-117 for METHOD=DNN).
+
+    The reference maps a result id to ``images_paths[i]`` from a fresh ``rglob`` at start-up
+    (backend/engine.py:61,112), so an image skipped at index time -- or a file added since --
+    shifts every later id.  ``indexer.main`` here persists the paths of
+    the rows it actually indexed beside the index; that list is used when present, the reference's
+    glob otherwise."""
     global index, images_paths, descriptor
-    images_paths = get_images_paths() if paths is None else paths
-    index = faiss.read_index(str(index_path or config.DNN_INDEX_PATH))
+    index_path = index_path or config.DNN_INDEX_PATH
+    index = faiss.read_index(str(index_path))
+    if paths is not None:
+        images_paths = paths
+    elif paths_file_for(index_path).exists():
+        from pathlib import Path
+
+        with open(paths_file_for(index_path)) as f:
+            images_paths = [Path(p) for p in json.load(f)]
+    else:
+        images_paths = get_images_paths()
+    if len(images_paths) != index.ntotal:
+        print(f"WARNING: {len(images_paths)} image paths for {index.ntotal} index rows: ids may not match paths")
     print(f"There are {index.ntotal} images in the index.")
     if desc is not None:
         descriptor = desc
@@ -81,9 +106,12 @@ def create_app():
 
     @app.route("/similar_images", methods=["POST"])
     def predict():
-        if not request.files:
+        if not request.files or "image" not in request.files:
             return Response("No file uploaded", status=400)
-        rgb = np.asarray(Image.open(io.BytesIO(request.files["image"].read())).convert("RGB"))
+        try:
+            rgb = np.asarray(Image.open(io.BytesIO(request.files["image"].read())).convert("RGB"))
+        except Exception:
+            return Response("Not an image", status=400)
         image = np.ascontiguousarray(rgb[:, :, ::-1])  # BGR like cv2.imdecode (backend/engine.py:42)
         start = time.time()
         if config.METHOD != Method.DNN:

@@ -3,6 +3,7 @@ paths -> describe_dataset -> np.concatenate -> create_search_index -> write_inde
 The BOVW and DHASH branches are outside the scoped hot path."""
 from __future__ import annotations
 
+import json
 import logging
 
 import numpy as np
@@ -29,6 +30,16 @@ def main():
     index = create_search_index(descriptions, index_type=config.INDEX_TYPE)
     config.DNN_INDEX_PATH.parent.mkdir(parents=True, exist_ok=True)
     faiss.write_index(index, str(config.DNN_INDEX_PATH))
+    # row id -> image path of the rows actually indexed (skipped images leave no row): the engine
+    # reads this instead of re-globbing the data folder (fixes SURVEY.md quirk 5.9-4)
+    from .engine import paths_file_for
+
+    described = [str(p) for p in np.asarray(describer.described_paths, dtype=object).ravel().tolist()]
+    if len(described) == index.ntotal:
+        with open(paths_file_for(config.DNN_INDEX_PATH), "w") as f:
+            json.dump(described, f)
+    else:  # descriptions came from somewhere that does not track paths (the cached joblib file, quirk 5.9-5)
+        print(f"WARNING: {len(described)} described paths for {index.ntotal} rows: no paths file written")
     return index
 
 

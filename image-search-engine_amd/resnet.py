@@ -4,8 +4,8 @@ The reference truncates torchvision's resnet50 at node ``flatten`` (2048-d,
 backend/descriptors.py:161-168).  The layer shapes below follow the published
 ResNet-50 v1.5 architecture that torchvision implements (stride on the 3x3
 convolution of each bottleneck); parameter names match torchvision's state_dict
-keys so IMAGENET1K_V2 weights load with ``load_state_dict`` where a checkpoint is
-available offline.  BASELINE config 2 uses seeded random-init weights (the
+keys so IMAGENET1K_V2 weights load where a checkpoint is available offline
+(``load_resnet50_weights``, ``CNNDescriptor(weights_path=...)``).  BASELINE config 2 uses seeded random-init weights (the
 reference fetches its weights from the network, which is impossible here).
 """
 from __future__ import annotations
@@ -85,6 +85,23 @@ def resnet50_features(seed: int | None = 0) -> ResNet50Features:
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
         return ResNet50Features()
+
+
+def load_resnet50_weights(net: ResNet50Features, path) -> ResNet50Features:
+    """Load a torchvision ResNet-50 ``state_dict`` (the file behind
+    ``resnet50(weights=IMAGENET1K_V2)``, backend/descriptors.py:161-163) into the extractor, BEFORE
+    BatchNorm is folded.  The file is read with ``weights_only=True`` (nothing in it is executed);
+    the classifier head ``fc.*`` is not part of the ``flatten`` feature node and is dropped; any
+    other missing or unexpected entry is an error."""
+    state = torch.load(str(path), map_location="cpu", weights_only=True)
+    if isinstance(state, dict) and "state_dict" in state and isinstance(state["state_dict"], dict):
+        state = state["state_dict"]
+    state = {k: v for k, v in state.items() if not k.startswith("fc.")}
+    missing, unexpected = net.load_state_dict(state, strict=False)
+    missing = [k for k in missing if not k.endswith("num_batches_tracked")]
+    if missing or unexpected:
+        raise RuntimeError(f"not a ResNet-50 state_dict: missing {missing[:5]}, unexpected {list(unexpected)[:5]}")
+    return net
 
 
 def fold_batchnorm_(net: ResNet50Features) -> ResNet50Features:

@@ -270,3 +270,37 @@ def test_bovw_histograms_batched_chunks_and_label_sweep(monkeypatch):
     ref = np.stack([np.histogram(clusterer.transform(X), bins=K)[0] if len(X) else np.zeros(K) for X in images])
     assert np.array_equal(H, ref.astype(np.float64))
     assert np.array_equal(bovw.create_visual_word_histogram([], clusterer, K), np.zeros((0, K)))
+
+
+def test_config2_cnn_embeddings_to_l2_index_end_to_end():
+    """BASELINE config 2 at a size the oracle covers: seeded random-init ResNet-50 (out_dim=512) on
+    seeded synthetic uint8 images -> create_search_index("l2") -> search; neighbour ids identical
+    to the exact CPU oracle on the very embeddings the index holds (backend/indexer.py:51-59,
+    backend/engine.py:46-57).  Post-ReLU CNN features share a large common component (|y|^2 of the
+    order 1e5 against neighbour distances below 1): the data that defeats an expanded-form kernel."""
+    from image_search_engine_amd.descriptors import CNNDescriptor
+    from image_search_engine_amd.utils import create_search_index
+    from oracle import knn_oracle as ko
+    from tests.knn_checks import assert_knn_matches
+
+    n, nq, k, d = 3000, 16, 10, 512
+    desc = CNNDescriptor(out_dim=d, seed=0)
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    feats = []
+    for i0 in range(0, n + nq, 250):
+        imgs = torch.randint(0, 256, (min(250, n + nq - i0), 224, 224, 3), generator=g, device="cuda",
+                             dtype=torch.uint8)
+        feats.append(desc.extract_features_tensor(imgs).cpu())
+    feats = torch.cat(feats).numpy()
+    xb, xq = np.ascontiguousarray(feats[:n]), np.ascontiguousarray(feats[n:])
+    assert xb.shape == (n, d) and np.isfinite(xb).all()
+    index = create_search_index(xb.copy(), index_type="l2")
+    D, I = index.search(xq, k)
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, ko.METRIC_L2)
+    n_mism = assert_knn_matches(D, I, D_ref, I_ref, xb, xq, ko.METRIC_L2, gap=ko.kth_gap(xb, xq, k, ko.METRIC_L2))
+    assert n_mism == 0
+    # a row of the index queried against itself comes back first at distance 0
+    D0, I0 = index.search(xb[17:18], 1)
+    assert I0[0, 0] == 17 and D0[0, 0] == 0.0
+    st = index.exact_stats()
+    assert st["reranked"] == nq + 1

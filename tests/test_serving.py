@@ -1,0 +1,217 @@
+"""The serving wire format (backend/engine.py:68-107 as the front end reads it,
+frontend/src/App.js:14-21,38-45) and the persisted row-id -> path list.
+
+CPU tests drive the Flask route with test doubles standing in for the descriptor and the index (the
+route itself is host logic); the GPU test runs it end to end on the MI355X: indexer.main ->
+engine.load -> POST /similar_images."""
+import base64
+import io
+import json
+
+import numpy as np
+import pytest
+
+from oracle import knn_oracle as ko
+
+
+def _png_bytes(arr_rgb):
+    from PIL import Image
+
+    buf = io.BytesIO()
+    Image.fromarray(arr_rgb).save(buf, format="PNG")
+    return buf.getvalue()
+
+
+def _write_images(folder, n, rng, size=48):
+    from PIL import Image
+
+    folder.mkdir(parents=True, exist_ok=True)
+    paths = []
+    for i in range(n):
+        arr = rng.integers(0, 256, (size, size, 3), dtype=np.uint8)
+        p = folder / f"img_{i:04d}.png"
+        Image.fromarray(arr).save(p)
+        paths.append(p)
+    return paths
+
+
+class _OracleIndex:
+    """Test double for faiss.IndexFlatL2 (tests only): exact search by the CPU oracle."""
+
+    def __init__(self, xb):
+        self.xb, self.d, self.ntotal = xb, xb.shape[1], xb.shape[0]
+
+    def search(self, x, k):
+        return ko.knn_exact(self.xb, np.asarray(x, dtype=np.float32), k, ko.METRIC_L2)
+
+
+class _MeanColourDescriptor:
+    """Test double for CNNDescriptor: the mean BGR colour tiled to d values, as a flat tensor."""
+
+    def __init__(self, d=12):
+        self.d = d
+        self.seen = []
+
+    def describe(self, image):
+        import torch
+
+        self.seen.append(image)
+        return torch.from_numpy(np.tile(image.reshape(-1, 3).mean(0), self.d // 3).astype(np.float32))
+
+
+@pytest.fixture
+def served(tmp_path):
+    pytest.importorskip("flask")
+    from image_search_engine_amd import engine
+
+    rng = np.random.default_rng(0)
+    paths = _write_images(tmp_path / "data", 30, rng)
+    desc = _MeanColourDescriptor()
+    from PIL import Image
+
+    feats = np.stack([desc.describe(np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1]).numpy() for p in paths])
+    saved = (engine.index, engine.images_paths, engine.descriptor)
+    engine.index, engine.images_paths, engine.descriptor = _OracleIndex(feats), paths + [tmp_path / "gone.png"], desc
+    yield engine, paths, feats
+    engine.index, engine.images_paths, engine.descriptor = saved
+
+
+def test_similar_images_wire_format(served):
+    engine, paths, feats = served
+    client = engine.create_app().test_client()
+    from PIL import Image
+
+    rgb = np.asarray(Image.open(paths[7]).convert("RGB"))
+    resp = client.post("/similar_images", data={"image": (io.BytesIO(_png_bytes(rgb)), "query.png")},
+                       content_type="multipart/form-data")
+    assert resp.status_code == 200 and resp.mimetype == "application/json"
+    assert resp.headers["Access-Control-Allow-Origin"] == "*"          # the reference enables CORS (engine.py:21)
+    body = json.loads(resp.data)
+    assert list(body.keys()) == ["prediction"]
+    pred = body["prediction"]
+    assert len(pred) == engine.config.NUM_IMAGES_TO_RETURN == 20      # backend/config.py:39
+    # every entry is [distance, base64 thumbnail | null, path] -- what App.js destructures as [dist, im, path]
+    for dist, im, path in pred:
+        assert isinstance(dist, float) and isinstance(path, str) and (im is None or isinstance(im, str))
+    assert pred[0][2] == str(paths[7]) and pred[0][0] == 0.0           # the uploaded image is its own best hit
+    assert [p[0] for p in pred] == sorted(p[0] for p in pred)          # ascending squared L2
+    thumb = Image.open(io.BytesIO(base64.decodebytes(pred[0][1].encode())))
+    assert thumb.format == "JPEG" and max(thumb.size) <= 256           # backend/utils.py:44-62
+    # the decoded upload reached the descriptor as BGR uint8 (cv2.imdecode order, backend/engine.py:42)
+    assert np.array_equal(engine.descriptor.seen[-1], rgb[:, :, ::-1])
+    D_ref, I_ref = ko.knn_exact(feats, feats[7:8], 20, ko.METRIC_L2)
+    assert [p[2] for p in pred] == [str(paths[i]) for i in I_ref[0]]
+    assert np.allclose([p[0] for p in pred], D_ref[0])
+
+
+def test_similar_images_errors_and_missing_files(served):
+    engine, paths, feats = served
+    client = engine.create_app().test_client()
+    assert client.post("/similar_images").status_code == 400                       # backend/engine.py:72-73
+    assert client.post("/similar_images", data={"other": "x"}).status_code == 400
+    bad = client.post("/similar_images", data={"image": (io.BytesIO(b"not an image"), "x.png")},
+                      content_type="multipart/form-data")
+    assert bad.status_code == 400
+    assert client.get("/similar_images").status_code == 405
+    # a hit whose file has vanished keeps its slot with a null thumbnail (backend/utils.py:51-54)
+    paths[3].unlink()
+    import torch
+
+    pred = engine.run_image_query(torch.from_numpy(feats[3]), 2)   # a flat tensor, as descriptor.describe returns
+    assert pred[0][1] is None and pred[0][2] == str(paths[3]) and pred[1][1] is not None
+    batched = engine.run_image_queries(feats[2:5], 3)
+    assert [len(b) for b in batched] == [3, 3, 3] and batched[1][0][2] == str(paths[3])
+
+
+def test_describe_dataset_tracks_the_paths_it_described(tmp_path, monkeypatch):
+    """A skipped image leaves no row: described_paths[i] is the path of row i (quirk 5.9-4)."""
+    from image_search_engine_amd import descriptors as ds
+
+    monkeypatch.setattr(ds.config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib")
+    rng = np.random.default_rng(1)
+    paths = _write_images(tmp_path / "data", 9, rng, size=16)
+    paths[4].write_bytes(b"broken")                       # undecodable -> printed and skipped
+    paths.insert(2, tmp_path / "data" / "missing.png")    # missing -> printed and skipped
+    desc = _MeanColourDescriptor()
+    describer = ds.Describer({"conv_features": desc}, batch_size=4)
+    out = ds.describe_dataset(describer, np.array(paths).reshape(-1, 1))
+    kept = [p for p in paths if p.name not in ("missing.png", paths[5].name)]
+    assert len(out) == 8 and describer.described_paths == kept
+    assert all(o.shape == (1, 12) for o in out)
+
+
+def test_load_resnet50_weights_roundtrip(tmp_path):
+    """CNNDescriptor(weights_path=...): a torchvision-style state_dict (with its fc head) is loaded
+    before BatchNorm is folded and reproduces the source network's features."""
+    import torch
+
+    from image_search_engine_amd.descriptors import CNNDescriptor
+    from image_search_engine_amd.resnet import load_resnet50_weights, resnet50_features
+
+    src = resnet50_features(seed=123).eval()
+    with torch.no_grad():  # non-trivial BatchNorm statistics, as a trained checkpoint has
+        for m in src.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    state = dict(src.state_dict())
+    state["fc.weight"] = torch.zeros(1000, 2048)
+    state["fc.bias"] = torch.zeros(1000)
+    path = tmp_path / "resnet50.pth"
+    torch.save(state, path)
+    x = torch.rand(2, 3, 64, 64)
+    with torch.no_grad():
+        want = src(x)
+    desc = CNNDescriptor(seed=0, device="cpu", weights_path=path)   # folds BatchNorm after loading
+    with torch.no_grad():
+        got = desc.feature_extractor(x)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-3)          # values are O(100): folding changes rounding only
+    assert not torch.allclose(CNNDescriptor(seed=0, device="cpu").feature_extractor(x), want, rtol=1e-2, atol=1.0)
+    torch.save({"conv1.weight": torch.zeros(64, 3, 7, 7)}, tmp_path / "bad.pth")
+    with pytest.raises(RuntimeError, match="not a ResNet-50"):
+        load_resnet50_weights(resnet50_features(0), tmp_path / "bad.pth")
+
+
+@pytest.mark.gpu
+def test_indexer_engine_route_end_to_end_on_gpu(tmp_path, monkeypatch):
+    """indexer.main (DNN branch, backend/indexer.py:51-59) -> paths file -> engine.load ->
+    POST /similar_images, with a broken image in the data folder: ids still map to the right files."""
+    pytest.importorskip("flask")
+    import torch
+
+    assert torch.cuda.is_available()
+    from PIL import Image
+
+    from image_search_engine_amd import descriptors as ds
+    from image_search_engine_amd import engine, indexer, utils
+
+    rng = np.random.default_rng(2)
+    data = tmp_path / "data"
+    paths = _write_images(data, 40, rng, size=64)
+    (data / "img_0005.png").write_bytes(b"broken")       # skipped at index time
+    models = tmp_path / "models"
+    for mod in (ds, engine, indexer, utils):
+        monkeypatch.setattr(mod.config, "DATA_FOLDER_PATH", data, raising=False)
+        monkeypatch.setattr(mod.config, "DNN_INDEX_PATH", models / "resnet50_dnn_index.faiss", raising=False)
+        monkeypatch.setattr(mod.config, "BOVW_CORNER_DESCRIPTIONS_PATH", models / "absent.joblib", raising=False)
+    index = indexer.main()
+    assert index.ntotal == 39
+    listed = json.loads(engine.paths_file_for(models / "resnet50_dnn_index.faiss").read_text())
+    assert len(listed) == 39 and str(data / "img_0005.png") not in listed
+    saved = (engine.index, engine.images_paths, engine.descriptor)
+    try:
+        engine.load(desc=ds.CNNDescriptor())
+        assert engine.index.ntotal == 39 and [str(p) for p in engine.images_paths] == listed
+        client = engine.create_app().test_client()
+        for probe in (3, 6, 39):                          # ids after the skipped image would be off by one with a fresh glob
+            rgb = np.asarray(Image.open(paths[probe]).convert("RGB"))
+            resp = client.post("/similar_images", data={"image": (io.BytesIO(_png_bytes(rgb)), "q.png")},
+                               content_type="multipart/form-data")
+            assert resp.status_code == 200
+            pred = json.loads(resp.data)["prediction"]
+            assert len(pred) == 20 and pred[0][2] == str(paths[probe]) and pred[0][0] <= 1e-3
+            assert [p[0] for p in pred] == sorted(p[0] for p in pred)
+    finally:
+        engine.index, engine.images_paths, engine.descriptor = saved
