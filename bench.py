@@ -334,9 +334,17 @@ def main():
             res["max_abs_dist_err"] = float(np.abs(Dn - Dc).max())
             st = local.exact_stats()
             res["exact_path"] = {"queries_reranked": st["reranked"], "queries_sent_to_exact_scan": st["exact_scan"]}
-            if not res["ids_identical"] or not res["max_abs_dist_err"] <= 1e-4:
-                sys.stderr.write("bench.py: PARITY GATE FAILED: " + json.dumps(res) + "\n")
-                raise SystemExit(3)  # north_star: identical ids, distances within 1e-4 (fp32)
+            # the gate (north_star: identical ids, distances within 1e-4 fp32): the tests' checker --
+            # ids bit-exact except where two rows' float64 distances are closer than float32 resolves
+            # (either order is then a correct float32 answer; the C oracle and the GPU sum in different
+            # orders), distances within the ABSOLUTE 1e-4
+            from tests.knn_checks import assert_knn_matches
+
+            try:
+                res["id_mismatches_at_float32_ties"] = assert_knn_matches(Dn, In, Dc, Ic, xb_full, xq_host, 1, atol=1e-4)
+            except AssertionError as e:
+                sys.stderr.write(f"bench.py: PARITY GATE FAILED ({e}): " + json.dumps(res) + "\n")
+                raise SystemExit(3)
         if sharded and world == 1:
             res["config"]["workload"] += " [rehearsal: sharded code path in a world of one]"
         sys.stdout.flush()

@@ -57,6 +57,10 @@ PROTOTYPES = [
     ("ise_normalize_rows_device", _int, [_vp, _i64, _int, _int, _vp]),
     ("ise_normalize_rows_host", _int, [_vp, _i64, _int, _int]),
     ("ise_bovw_histogram_device", _int, [_vp, _vp, _i64, _int, _vp, _int, _vp]),
+    ("ise_comm_unique_id", _int, [_vp]),
+    ("ise_comm_create", _int, [ctypes.POINTER(_vp), _vp, _int, _int, _int]),
+    ("ise_comm_allgather_keys", _int, [_vp, _vp, _vp, _i64, _vp]),
+    ("ise_comm_destroy", _int, [_vp]),
     ("ise_index_search_timed_device", _int,
      [_vp, _vp, _i64, _int, _vp, _vp, _vp, _int, _f32p, _f32p]),
 ]

@@ -41,6 +41,7 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+int ise_fail_(int code, const std::string& msg) { return fail(code, msg); }  // for the other translation units
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \

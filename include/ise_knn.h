@@ -127,6 +127,24 @@ int ise_index_search_keys_device(ise_index_t* h, const float* q_dev, int64_t nq,
 int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int64_t nq, int k,
                           int metric, float* D_dev, int64_t* I_dev, int device, void* stream);
 
+/* The exchange step of the row-sharded search (the reference itself never shards:
+ * one in-RAM IndexFlat, backend/utils.py:327): ONE all-gather of every rank's packed candidates,
+ * issued by RCCL on the caller's stream between the shard scans and the merge -- no host
+ * synchronisation, no framework in between.
+ *   ise_comm_unique_id   rank 0 draws the 128-byte id of a new communicator; the caller hands it to
+ *                        the other ranks (any channel; sharded.py uses one torch.distributed broadcast)
+ *   ise_comm_create      every rank, collectively: join as `rank` of `world`, one GPU per rank
+ *   ise_comm_allgather_keys  recv[r * count + i] = rank r's send[i] on every rank (count uint64 per
+ *                        rank, device pointers); enqueued on `stream`, returns at once
+ * librccl is resolved at run time, so the library loads without it; these entry points then
+ * return ISE_E_NODEVICE. */
+typedef struct ise_comm ise_comm_t;
+int ise_comm_unique_id(void* id128);
+int ise_comm_create(ise_comm_t** out, const void* id128, int world, int rank, int device);
+int ise_comm_allgather_keys(ise_comm_t* c, const uint64_t* send_dev, uint64_t* recv_dev,
+                            int64_t count, void* stream);
+int ise_comm_destroy(ise_comm_t* c);
+
 /* index.search(X, 1) for MANY rows against a SMALL index: nearest-centroid assignment,
  * FaissKMeans.transform (backend/kmeans_faiss.py:46-50; BASELINE config 4).  X: n x d
  * float32 on the device; I: n int64 (row of the best index entry, -1 if none); D: n

@@ -19,12 +19,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class OracleShardBackend:
     """Test double for HipShardBackend: same interface, oracle arithmetic."""
 
-    def __init__(self, d, metric):
+    def __init__(self, d, metric, storage="f32"):
         from oracle import knn_oracle as ko
 
         self.ko, self.d, self.metric = ko, d, metric
         self.xb = np.zeros((0, d), np.float32)
         self.device = torch.device("cpu")
+        # bf16 storage (BASELINE config 5): rows and queries are rounded to bf16, candidates are
+        # float32 scores of the rounded values
+        self.rnd = (lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16)
+                    .to(torch.float32).numpy()) if storage == "bf16" else (lambda a: a)
 
     @property
     def ntotal(self):
@@ -32,12 +36,12 @@ class OracleShardBackend:
 
     def add(self, x):
         x = x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
-        self.xb = np.concatenate([self.xb, x.astype(np.float32)])
+        self.xb = np.concatenate([self.xb, self.rnd(x.astype(np.float32))])
 
     def local_search_keys(self, xq, k, id_base):
         from tests import keycodec as kc
 
-        D, I = self.ko.knn_exact(self.xb, xq.numpy(), k, self.metric, id_offset=id_base)
+        D, I = self.ko.knn_exact(self.xb, self.rnd(xq.numpy()), k, self.metric, id_offset=id_base)
         return torch.from_numpy(kc.encode(D, I, self.metric).view(np.int64))
 
     def merge(self, keys_all):
@@ -49,7 +53,7 @@ class OracleShardBackend:
         return torch.from_numpy(D), torch.from_numpy(I)
 
 
-def _worker(rank, world, port, metric, n, q):
+def _worker(rank, world, port, metric, n, q, storage="f32"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -65,8 +69,11 @@ def _worker(rank, world, port, metric, n, q):
             xb[n - 3] = xb[2]  # duplicate across shards: tie must go to the lower global id
         xq = np.concatenate([rng.random((4, d), dtype=np.float32), xb[2:3]]) if n > 2 else \
             rng.random((3, d), dtype=np.float32)
-        idx = ShardedIndexFlat(d, metric, backend=OracleShardBackend(d, metric))
+        idx = ShardedIndexFlat(d, metric, backend=OracleShardBackend(d, metric, storage))
+        assert idx.collective == "torch" and idx.comm is None  # a CPU group never takes the RCCL path
         idx.add_global(xb)
+        if storage == "bf16":  # what the answers are compared with: the oracle on the rounded values
+            xb, xq = idx.backend.rnd(xb), idx.backend.rnd(xq)
         lo, hi = ShardedIndexFlat.shard_bounds(n, world, rank)
         assert idx.backend.ntotal == hi - lo and idx.id_base == lo and idx.ntotal == n
         tq = torch.from_numpy(xq)
@@ -96,7 +103,7 @@ def _worker(rank, world, port, metric, n, q):
         got += [(Dg.clone(), Ig.clone()) for Dg, Ig in pipe.flush()]
         assert len(got) == len(batches)
         for bq, (Dg, Ig) in zip(batches, got):
-            Db, Ib = ko.knn_exact(xb, bq, k, metric)
+            Db, Ib = ko.knn_exact(xb, idx.backend.rnd(bq), k, metric)
             assert np.array_equal(Ig.numpy(), Ib) and np.array_equal(Dg.numpy(), Db)
         assert pipe.flush() == []
         with pytest.raises(ValueError):
@@ -124,13 +131,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("metric", [1, 0])
-@pytest.mark.parametrize("n", [1001, 3])
-def test_world2_gloo_sharded_search_equals_unsharded(metric, n):
+@pytest.mark.parametrize("metric,n,storage", [(1, 1001, "f32"), (1, 3, "f32"), (0, 1001, "f32"), (0, 3, "f32"),
+                                              (0, 1001, "bf16")])
+def test_world2_gloo_sharded_search_equals_unsharded(metric, n, storage):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, metric, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, metric, n, q, storage)) for r in range(2)]
     [p.start() for p in procs]
     res = [q.get(timeout=120) for _ in procs]
     [p.join(timeout=60) for p in procs]

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, backend, q):
+def _worker(rank, world, port, backend, q, metric=1, storage="f32", collective="auto"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,19 +36,27 @@ def _worker(rank, world, port, backend, q):
 
         rng = np.random.default_rng(11)
         n, d, nq, k = 30011, 96, 16, 10
-        xb = rng.random((n, d), dtype=np.float32)
+        xb = rng.random((n, d), dtype=np.float32) - np.float32(0.5 if metric == 0 else 0.0)
         xb[n - 5] = xb[7]  # duplicate rows in different shards: the lower global id wins
-        idx = ShardedIndexFlat(d, faiss.METRIC_L2)
+        idx = ShardedIndexFlat(d, metric, storage=storage, collective=collective)
+        assert idx.collective == ("rccl" if (backend == "nccl" and collective != "torch") else "torch")
         idx.add_global(torch.from_numpy(xb).to(dev))
         lo, hi = ShardedIndexFlat.shard_bounds(n, world, rank)
         assert idx.backend.ntotal == hi - lo and idx.id_base == lo and idx.ntotal == n
 
-        batches = [rng.random((nq, d), dtype=np.float32) for _ in range(11)]
+        batches = [rng.random((nq, d), dtype=np.float32) - np.float32(0.5 if metric == 0 else 0.0) for _ in range(11)]
         batches[3][0] = xb[7]
+        if storage == "bf16":  # the oracle sees the values the bf16 index holds (queries are rounded too)
+            rnd = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()  # noqa: E731
+            xb_o = rnd(xb)
+        else:
+            rnd = lambda a: a  # noqa: E731
+            xb_o = xb
         D, I = idx.search(torch.from_numpy(batches[3]).to(dev), k)
-        Dr, Ir, _ = fo.knn_flat(xb, batches[3], k, 1, 4)
-        assert_knn_matches(D.cpu().numpy(), I.cpu().numpy(), Dr, Ir, xb, batches[3], 1)
-        assert I[0, 0].item() == 7 and I[0, 1].item() == n - 5
+        Dr, Ir, _ = fo.knn_flat(xb_o, rnd(batches[3]), k, metric, 4)
+        assert_knn_matches(D.cpu().numpy(), I.cpu().numpy(), Dr, Ir, xb_o, rnd(batches[3]), metric)
+        if metric == 1:
+            assert I[0, 0].item() == 7 and I[0, 1].item() == n - 5
 
         # 11 batches through buckets of 4 on a ring of 2 buffer sets: two full buckets and a
         # partial one; results are copied out as they are handed back (the ring is reused)
@@ -60,8 +68,8 @@ def _worker(rank, world, port, backend, q):
         got += [(Dg.clone(), Ig.clone()) for Dg, Ig in pipe.flush()]
         assert len(got) == len(batches)
         for b, (Dg, Ig) in zip(batches, got):
-            Db, Ib, _ = fo.knn_flat(xb, b, k, 1, 4)
-            assert_knn_matches(Dg.cpu().numpy(), Ig.cpu().numpy(), Db, Ib, xb, b, 1)
+            Db, Ib, _ = fo.knn_flat(xb_o, rnd(b), k, metric, 4)
+            assert_knn_matches(Dg.cpu().numpy(), Ig.cpu().numpy(), Db, Ib, xb_o, rnd(b), metric)
         # the pipeline and the one-batch form agree bit for bit
         D1, I1 = idx.search(dq[10], k)
         assert torch.equal(I1, got[10][1]) and torch.equal(D1, got[10][0])
@@ -83,12 +91,20 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
-def test_sharded_hip_backend(backend, world):
+@pytest.mark.parametrize("backend,world,metric,storage,collective", [
+    ("gloo", 2, 1, "f32", "auto"),     # two ranks share the card: torch.distributed over gloo
+    ("nccl", 1, 1, "f32", "auto"),     # the library's own RCCL communicator (ise_comm_*), as the 8-GPU run uses it
+    ("nccl", 1, 1, "f32", "torch"),    # the same through torch.distributed
+    ("gloo", 2, 0, "f32", "auto"),     # inner product
+    ("gloo", 2, 0, "bf16", "auto"),    # BASELINE config 5: bf16 rows, inner product
+    ("nccl", 1, 0, "bf16", "auto"),
+])
+def test_sharded_hip_backend(backend, world, metric, storage, collective):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, metric, storage, collective))
+             for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=300) for _ in procs]
     [p.join(timeout=60) for p in procs]
