@@ -70,3 +70,13 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+
+// dev builds (-DISE_ABLATE): block 0 / lane 0 stamps the 100 MHz real-time clock into a debug buffer
+#ifdef ISE_ABLATE
+#define DBG_STAMP(buf, i)                                                                   \
+    do {                                                                                    \
+        if ((buf) && blockIdx.x == 0 && threadIdx.x == 0) (buf)[(i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define DBG_STAMP(buf, i) do {} while (0)
+#endif

@@ -125,20 +125,31 @@ __host__ __device__ constexpr size_t rerank_lds_bytes(int dp, int kc) {
     return (size_t)dp * 4 + (size_t)kc * 8 + (size_t)rerank_pow2(kc) * 8;
 }
 
-// Re-rank the kc candidates of query q (kin: ascending lo-keys, KEY_PAD padded, in LDS) by their
-// direct-difference distance; emit the top k; on a failed certificate put q on the fallback list.
-// Called by all 256 threads of the block; smem is the block's dynamic LDS (rerank_lds_bytes).
-__device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsigned char* smem, bool kin_loaded,
+// The query of a rerank block into LDS (zero padded to dp).  Separate from rerank_block so that the
+// fused merge kernel can issue it before the lists are merged.
+template <int NT>
+__device__ __forceinline__ void rerank_stage_query(const ExactParams& p, int q, unsigned char* smem) {
+    float* qs = reinterpret_cast<float*>(smem);
+    const float* src = p.q + (size_t)q * p.d;
+    for (int j = threadIdx.x; j < p.dp; j += NT) qs[j] = j < p.d ? src[j] : 0.f;
+}
+
+// Re-rank the kc candidates of query q (kin: ascending lo-keys, KEY_PAD padded, in LDS behind the
+// staged query) by their direct-difference distance; emit the top k; on a failed certificate put q
+// on the fallback list.  Called by all NT threads of the block; smem is the block's dynamic LDS
+// (rerank_lds_bytes).  keys_in_global: candidates to load first, or null when kin is already filled.
+template <int NT>
+__device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsigned char* smem,
                                              const u64* keys_in_global) {
+    constexpr int NW = NT / 64;
     float* qs = reinterpret_cast<float*>(smem);
     u64* kin = reinterpret_cast<u64*>(qs + p.dp);
     u64* kex = kin + p.kc;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n2 = rerank_pow2(p.kc);
-    const float* src = p.q + (size_t)q * p.d;
-    for (int j = tid; j < p.dp; j += 256) qs[j] = j < p.d ? src[j] : 0.f;
-    if (!kin_loaded)
-        for (int c = tid; c < p.kc; c += 256) kin[c] = keys_in_global[(size_t)q * p.kc + c];
+    DBG_STAMP(p.stats ? p.stats + 8 : nullptr, 3);
+    if (keys_in_global)
+        for (int c = tid; c < p.kc; c += NT) kin[c] = keys_in_global[(size_t)q * p.kc + c];
     __syncthreads();
     // real entries come first (the list is sorted and pads are the largest key)
     int count = 0;
@@ -146,8 +157,9 @@ __device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsign
         const bool real = (c0 + lane) < p.kc && kin[c0 + lane] != KEY_PAD;
         count += __popcll(__ballot(real));
     }
-    constexpr int R = 4;
-    for (int c0 = w * R; c0 < n2; c0 += 4 * R) {
+    DBG_STAMP(p.stats ? p.stats + 8 : nullptr, 4);
+    constexpr int R = NW >= 8 ? 2 : 4;  // rows in flight per wave
+    for (int c0 = w * R; c0 < n2; c0 += NW * R) {
         if (c0 >= count) {  // nothing real from here on (and no row to read when the index is empty)
             if (lane < R && c0 + lane < n2) kex[c0 + lane] = KEY_PAD;
             continue;
@@ -170,7 +182,24 @@ __device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsign
                     kex[c0 + r] = kc_[r] != KEY_PAD ? (((u64)ord_f32(dd[r]) << 32) | (uint32_t)kc_[r]) : KEY_PAD;
         }
     }
-    block_sort_u64(kex, n2, tid, 256);
+    DBG_STAMP(p.stats ? p.stats + 8 : nullptr, 5);
+    if (n2 <= 64) {  // one wave ranks all pairs: no barrier per stage
+        __syncthreads();
+        if (w == 0) {
+            const u64 mine = lane < n2 ? kex[lane] : KEY_PAD;
+            int rk = 0;
+            for (int j = 0; j < n2; j++) rk += readlane_u64(mine, j) < mine ? 1 : 0;
+            // pads are equal: they keep their slots' worth of the tail in any order
+            const u64 padm = __ballot(mine == KEY_PAD) & ((lane < 63 ? (1ull << (lane + 1)) : 0ull) - 1ull);
+            if (mine == KEY_PAD) rk += __popcll(padm) - 1;
+            wave_lds_fence();
+            if (lane < n2) kex[rk] = mine;
+        }
+        __syncthreads();
+    } else {
+        block_sort_u64(kex, n2, tid, NT);
+    }
+    DBG_STAMP(p.stats ? p.stats + 8 : nullptr, 6);
     // certificate: lo of the last candidate strictly above the k-th direct distance.  A list that is
     // not full holds every admissible row of the index.
     bool ok = true;
@@ -180,7 +209,8 @@ __device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsign
         ok = lo_last > d_k;  // false on NaN
     }
     if (p.force_fail) ok = false;
-    for (int r = tid; r < p.k; r += 256) emit_exact(p, (size_t)q * p.k + r, r < count ? kex[r] : KEY_PAD);
+    for (int r = tid; r < p.k; r += NT) emit_exact(p, (size_t)q * p.k + r, r < count ? kex[r] : KEY_PAD);
+    DBG_STAMP(p.stats ? p.stats + 8 : nullptr, 7);
     if (tid == 0) {
         if (p.stats) atomicAdd(&p.stats[0], 1ull);
         if (!ok) {
@@ -193,137 +223,7 @@ __device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsign
 // standalone form: candidates [nq][kc] in HBM (the multi-pass path, kc > 32)
 __global__ __launch_bounds__(256) void rerank_kernel(const ExactParams p, const u64* keys_in) {
     extern __shared__ __align__(16) unsigned char smem_rr[];
-    rerank_block(p, (int)blockIdx.x, smem_rr, false, keys_in);
+    rerank_stage_query<256>(p, (int)blockIdx.x, smem_rr);
+    rerank_block<256>(p, (int)blockIdx.x, smem_rr, keys_in);
 }
 
-// ---------------------------------------------------------------- exact fallback scan
-// Direct-difference scan of the whole index for the queries on the launch's fallback list -- the
-// algorithm Faiss runs for nq < 20 (fvec_L2sqr per pair + a k-heap), restated for the GPU: a block
-// owns a contiguous slab of rows, a wave scores XR rows against XQ listed queries at a time with the
-// same d() as the rerank, and keeps its k best per query as a sorted list spread over its lanes
-// (insertion by ballot rank).  Exits at once when the list is empty (the common case).
-//   part: [list position][gridDim.x][kpass] sorted keys per block, merged by merge_kernel (gated)
-//   floor_keys: optional [list position] -- only keys above it enter (k > 32: one exact pass per 32)
-#define XQ 4
-#define XR 2
-struct ExactScanParams {
-    const float* xb;
-    const float* q;
-    long long n;
-    int d, dp;
-    int kpass;  // <= 32
-    uint32_t id_base;
-    const u64* fl_state;
-    const int* fl_list;
-    uint32_t seq;
-    const u64* floor_keys;  // [list position] or null
-    u64* part;
-    long long rows_per_block;
-};
-
-__device__ __forceinline__ u64 shfl_up1_u64(u64 v) {
-    const int lo = __shfl_up((int)(uint32_t)v, 1), hi = __shfl_up((int)(uint32_t)(v >> 32), 1);
-    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-
-__global__ __launch_bounds__(256) void exact_scan_kernel(const ExactScanParams p) {
-    const u64 st = __hip_atomic_load(p.fl_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(st >> 32) != p.seq) return;  // no certificate failed in this launch
-    const int nfl = (int)(uint32_t)st;
-    extern __shared__ __align__(16) unsigned char smem_xs[];
-    float* qs = reinterpret_cast<float*>(smem_xs);            // [XQ][dp]
-    u64* wl = reinterpret_cast<u64*>(qs + (size_t)XQ * p.dp);  // [XQ][4 waves][32]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
-    const long long r_end = min(p.n, r_begin + p.rows_per_block);
-    const int kp = p.kpass;
-    for (int g0 = 0; g0 < nfl; g0 += XQ) {
-        const int ng = min(XQ, nfl - g0);
-        __syncthreads();  // the previous group's LDS is dead
-        for (int i = tid; i < XQ * p.dp; i += 256) {
-            const int gq = i / p.dp, j = i - gq * p.dp;
-            float v = 0.f;
-            if (gq < ng && j < p.d) v = p.q[(size_t)p.fl_list[g0 + gq] * p.d + j];
-            qs[i] = v;
-        }
-        __syncthreads();
-        u64 lst[XQ], tau[XQ], flo[XQ];
-#pragma unroll
-        for (int gq = 0; gq < XQ; gq++) {
-            lst[gq] = KEY_PAD;
-            tau[gq] = TAU0;
-            flo[gq] = (p.floor_keys && gq < ng) ? p.floor_keys[g0 + gq] : 0ull;
-        }
-        for (long long r0 = r_begin + (long long)w * XR; r0 < r_end; r0 += 4 * XR) {
-            float s[XQ][XR];
-#pragma unroll
-            for (int gq = 0; gq < XQ; gq++)
-#pragma unroll
-                for (int r = 0; r < XR; r++) s[gq][r] = 0.f;
-            for (int j = lane * 4; j < p.dp; j += 256) {
-                f32x4 y[XR];
-#pragma unroll
-                for (int r = 0; r < XR; r++) {
-                    const long long row = min(r0 + r, r_end - 1);
-                    y[r] = *reinterpret_cast<const f32x4*>(p.xb + (size_t)row * p.dp + j);
-                }
-#pragma unroll
-                for (int gq = 0; gq < XQ; gq++) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(qs + (size_t)gq * p.dp + j);
-#pragma unroll
-                    for (int r = 0; r < XR; r++) {
-                        const f32x4 t = y[r] - x;
-                        s[gq][r] = fmaf(t[0], t[0], s[gq][r]);
-                        s[gq][r] = fmaf(t[1], t[1], s[gq][r]);
-                        s[gq][r] = fmaf(t[2], t[2], s[gq][r]);
-                        s[gq][r] = fmaf(t[3], t[3], s[gq][r]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int gq = 0; gq < XQ; gq++)
-#pragma unroll
-                for (int r = 0; r < XR; r++) {
-                    const float dd = wave_sum_f32(s[gq][r]);  // the same on every lane
-                    const u64 kj = ((u64)ord_f32(dd) << 32) | (uint32_t)((uint32_t)(r0 + r) + p.id_base);
-                    const bool ok = (r0 + r < r_end) && gq < ng && dd < FLT_MAX && kj < tau[gq] && kj > flo[gq];
-                    if (ok) {  // wave-uniform
-                        const int pos = __popcll(__ballot(lst[gq] < kj));
-                        const u64 up = shfl_up1_u64(lst[gq]);
-                        lst[gq] = lane < pos ? lst[gq] : (lane == pos ? kj : up);
-                        if (lane >= kp) lst[gq] = KEY_PAD;
-                        const u64 kth = readlane_u64(lst[gq], kp - 1);
-                        tau[gq] = kth == KEY_PAD ? TAU0 : kth;
-                    }
-                }
-        }
-#pragma unroll
-        for (int gq = 0; gq < XQ; gq++)
-            if (lane < 32) wl[(gq * 4 + w) * 32 + lane] = lst[gq];
-        __syncthreads();
-        if (w < ng) {  // wave w folds the four wave lists of listed query g0 + w
-            u64 kk[2];
-            kk[0] = wl[(w * 4) * 32 + lane];        // waves 0, 1
-            kk[1] = wl[(w * 4 + 2) * 32 + lane];    // waves 2, 3
-            u64* out = p.part + ((size_t)(g0 + w) * gridDim.x + blockIdx.x) * kp;
-            u64 kth_unused;
-            const int nw = wave_select<2>(kk, 128, kp, out, &kth_unused);
-            if (lane >= nw && lane < kp) out[lane] = KEY_PAD;
-        }
-    }
-}
-
-// k > 32 on the exact path: copy one exact pass's keys [list position][kp] into the final outputs at
-// column `off` and keep each query's last key as the floor of the next pass
-__global__ __launch_bounds__(256) void exact_scatter_kernel(const ExactParams p, const u64* pass_keys, int kp, int off,
-                                                            u64* floor_out) {
-    const u64 st = __hip_atomic_load(p.fl_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(st >> 32) != p.seq) return;
-    const int nfl = (int)(uint32_t)st;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nfl * kp) return;
-    const int pos = i / kp, r = i - pos * kp;
-    const u64 key = pass_keys[i];
-    if (off + r < p.k) emit_exact(p, (size_t)p.fl_list[pos] * p.k + off + r, key);
-    if (r == kp - 1) floor_out[pos] = key;  // KEY_PAD when the index ran out: later passes admit nothing
-}

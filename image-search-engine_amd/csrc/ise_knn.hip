@@ -33,6 +33,7 @@
 #include "ise_assign.hpp"
 #include "ise_exact.hpp"
 #include "ise_merge.hpp"
+#include "ise_exact_scan.hpp"
 #include "ise_rows.hpp"
 
 // ---------------------------------------------------------------- host side
@@ -204,8 +205,8 @@ extern "C" int ise_index_create_ex(ise_index_t** out, int d, int metric, int dev
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&h->mu, (size_t)h->dp * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->mu, 0, (size_t)h->dp * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&h->stats_dev, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(h->stats_dev, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->stats_dev, 32 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->stats_dev, 0, 32 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         if (h->stream) (void)hipStreamDestroy(h->stream);
         if (h->mu) (void)hipFree(h->mu);
@@ -604,7 +605,7 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     const int max_useful = (pl->tiles_total + pl->waves - 1) / pl->waves;
     if (nb > max_useful) nb = max_useful;
     if (nb < 1) nb = 1;
-    if (nb > MERGE_THREADS * MERGE_LPT) nb = MERGE_THREADS * MERGE_LPT;
+    if (nb > MERGE_LISTS_MAX) nb = MERGE_LISTS_MAX;
     pl->tiles_per_block = (pl->tiles_total + nb - 1) / nb;
     if (pl->tiles_per_block < 1) pl->tiles_per_block = 1;
     pl->nblocks = (pl->tiles_total + pl->tiles_per_block - 1) / pl->tiles_per_block;
@@ -653,8 +654,8 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
     }
     if (pl.exact) {
         if (!w->fl_state) {
-            HIP_TRY(hipMalloc(&w->fl_state, sizeof(u64)));
-            HIP_TRY(hipMemset(w->fl_state, 0, sizeof(u64)));  // tag 0 is never issued
+            HIP_TRY(hipMalloc(&w->fl_state, 2 * sizeof(u64)));  // [0] the list's state, [1] the exact scan's arrival counter
+            HIP_TRY(hipMemset(w->fl_state, 0, 2 * sizeof(u64)));  // tag 0 is never issued
             w->fl_seq = 0;
             if (const char* e = getenv("ISE_XCHG_SEQ_START")) w->fl_seq = (uint32_t)strtoul(e, nullptr, 0);
             *changed = true;
@@ -739,7 +740,7 @@ static void launch_merge(unsigned grid, size_t lds, hipStream_t st, const MergeP
 
 // The exact fallback scan for the queries the rerank put on the slot's list: launched behind every
 // rerank and gated on the GPU (nothing is read back on the way), so a launch without failed
-// certificates costs two kernels that exit at once.  k <= 32: one exact pass written straight to
+// certificates costs one kernel that exits at once.  k <= 32: one exact pass written straight to
 // the outputs; larger k: one pass per 32 results, floor-keyed like the filter passes.
 static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const ScanPlan& pl, const ExactParams& xp,
                                   long long nq, hipStream_t st) {
@@ -748,17 +749,17 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
     xs.id_base = xp.id_base; xs.fl_state = w->fl_state; xs.fl_list = w->fl_list; xs.seq = xp.seq;
     xs.part = w->part;  // the filter's lists are dead: [position][nblocks][kp] fits (kp <= kpass, positions <= nq)
     xs.rows_per_block = (long long)pl.tiles_per_block * 16;
+    xs.arrive = reinterpret_cast<unsigned int*>(w->fl_state + 1);
     const size_t lds = (size_t)XQ * h->dp * 4 + (size_t)XQ * 4 * 32 * 8;
-    MergeParams mp;
+    MergeParams mp;  // the per-block lists are merged by the scan's last block
     mp.lists = w->part; mp.qt = 1; mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.metric = h->metric;
-    mp.fl_state = w->fl_state; mp.fl_list = w->fl_list; mp.seq = xp.seq;
+    mp.fl_state = w->fl_state; mp.fl_list = w->fl_list; mp.seq = xp.seq; mp.dbg = nullptr;
     const int k = xp.k;
     if (k <= KPASS_MAX) {
         xs.kpass = k; xs.floor_keys = nullptr;
-        hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs);
         mp.k = k; mp.stride_list = k; mp.stride_qtile = (long long)pl.nblocks * k;
         mp.D = xp.D; mp.I = xp.I; mp.keys_out = xp.keys_out; mp.out_by_pos = 0;
-        launch_merge<false>((unsigned)nq, 0, st, mp, xp);
+        hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs, mp);
         HIP_TRY(hipGetLastError());
         return ISE_OK;
     }
@@ -767,10 +768,9 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
     const int kp = KPASS_MAX;
     for (int off = 0; off < k; off += kp) {
         xs.kpass = kp; xs.floor_keys = off ? fb_floor : nullptr;
-        hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs);
         mp.k = kp; mp.stride_list = kp; mp.stride_qtile = (long long)pl.nblocks * kp;
         mp.D = nullptr; mp.I = nullptr; mp.keys_out = fb_pass; mp.out_by_pos = 1;
-        launch_merge<false>((unsigned)nq, 0, st, mp, xp);
+        hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs, mp);
         const long long tot = nq * kp;
         hipLaunchKernelGGL(exact_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, xp,
                            (const u64*)fb_pass, kp, off, fb_floor);
@@ -829,6 +829,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     mp.stride_qtile = (long long)pl.nblocks * NQ * pl.kpass; mp.qt = NQ;
     mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.k = pl.kpass; mp.metric = h->metric;
     mp.fl_state = nullptr; mp.fl_list = nullptr; mp.seq = 0; mp.out_by_pos = 0;
+    mp.dbg = h->stats_dev + 8;
 
     ExactParams xp;  // used on the exact path only
     xp.xb = (const float*)h->xb; xp.q = q_dev; xp.n = h->n; xp.d = h->d; xp.dp = h->dp; xp.nq = (int)nq;
@@ -1046,6 +1047,16 @@ extern "C" int ise_index_stats(ise_index_t* h, uint64_t* out4) {
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long tmp[4];
     HIP_TRY(hipMemcpy(tmp, h->stats_dev, sizeof(tmp), hipMemcpyDeviceToHost));
+#ifdef ISE_ABLATE
+    if (getenv("ISE_DEBUG_STAMPS")) {  // dev: merge + rerank phase stamps of block 0 (100 MHz ticks)
+        unsigned long long st[16];
+        if (hipMemcpy(st, h->stats_dev + 8, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "merge/rerank stamps (us since kernel entry):");
+            for (int i = 1; i < 8; i++) fprintf(stderr, " [%d] %.2f", i, (double)(long long)(st[i] - st[0]) / 100.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     out4[0] = tmp[0];
     out4[1] = tmp[1];
     out4[2] = h->mu_updates;
@@ -1125,7 +1136,7 @@ extern "C" int ise_index_assign_device(ise_index_t* h, const float* x_dev, int64
 extern "C" int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int64_t nq, int k, int metric, float* D_dev,
                                      int64_t* I_dev, int device, void* stream) {
     if (!keys_dev || !D_dev || !I_dev) return fail(ISE_E_INVALID, "NULL pointer");
-    if (n_lists <= 0 || n_lists > MERGE_THREADS * MERGE_LPT) return fail(ISE_E_INVALID, "n_lists must be in [1, 1024]");
+    if (n_lists <= 0 || n_lists > MERGE_LISTS_MAX) return fail(ISE_E_INVALID, "n_lists must be in [1, 1024]");
     if (k <= 0 || k > ISE_MAX_K || nq < 0 || nq > (1ll << 20)) return fail(ISE_E_INVALID, "bad nq / k");
     if (metric != ISE_METRIC_L2 && metric != ISE_METRIC_INNER_PRODUCT) return fail(ISE_E_INVALID, "bad metric");
     if (nq == 0) return ISE_OK;
@@ -1136,7 +1147,7 @@ extern "C" int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int6
     mp.stride_qtile = (long long)k; mp.qt = 1;
     mp.n_lists = n_lists; mp.nq = (int)nq; mp.k = k; mp.metric = metric;
     mp.D = D_dev; mp.I = (long long*)I_dev; mp.keys_out = nullptr;
-    mp.fl_state = nullptr; mp.fl_list = nullptr; mp.seq = 0; mp.out_by_pos = 0;
+    mp.fl_state = nullptr; mp.fl_list = nullptr; mp.seq = 0; mp.out_by_pos = 0; mp.dbg = nullptr;
     if (n_lists <= 64)
         hipLaunchKernelGGL(merge_small_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mp);
     else
