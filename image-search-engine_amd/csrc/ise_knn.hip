@@ -518,8 +518,14 @@ struct ScanPlan {
 };
 
 // candidates kept beyond k on the exact path: enough that the certificate holds on data whose
-// neighbour spacing exceeds the bound's width (6 spare slots at k <= 10 fit the 16-slot lists)
-static int exact_extra(int k) { return k <= 10 ? 6 : (k <= 12 ? 16 - k : 4); }
+// neighbour spacing exceeds the bound's width.  4 keeps k + extra below the 16-slot block lists at
+// k <= 11, so that the boot's windowed cut has a window ([kc, kb]) instead of one exact rank
+// (overridable for experiments: $ISE_EXACT_EXTRA)
+static int exact_extra(int k) {
+    static const int forced = [] { const char* e = getenv("ISE_EXACT_EXTRA"); return e ? atoi(e) : 0; }();
+    (void)k;
+    return forced > 0 && forced <= 16 ? forced : 4;
+}
 // relative width of the scan's lower bound: every rounding between the stored floats and the keyed
 // value, in units of u = 2^-24 times (|x-mu|^2 + |y-mu|^2) (derivation: DESIGN.md section 4.1)
 static float exact_beta(const ise_index* h) { return (0.5625f * h->dp + 256.f) * 5.9604645e-8f * 1.02f; }
