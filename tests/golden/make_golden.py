@@ -115,5 +115,32 @@ def main():
     emit("l2_shard8_n1000_d32_k10", xb, xq, 10, L2)
 
 
+def emit_seeded(name, kind, seed, n, d, nq, k, metric):
+    """SURVEY.md 8c's full-size fixtures, stored as seed + expected outputs (tests/knn_checks.py
+    regenerates the inputs): the arrays themselves would be megabytes."""
+    from tests.knn_checks import seeded_inputs
+
+    xb, xq = seeded_inputs(kind, seed, n, d, nq)
+    D, I = ko.knn_exact(xb, xq, k, metric)
+    gap = ko.kth_gap(xb, xq, k, metric)
+    crosscheck(xb, xq, k, metric, I, D)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), kind=kind, seed=np.int64(seed), n=np.int64(n), d=np.int64(d),
+                        nq=np.int64(nq), k=np.int64(k), metric=np.int64(metric), I=I, D=D, gap=gap)
+    print(f"{name:34s} N={n:5d} d={d:4d} nq={nq:4d} k={k:3d} min gap {gap.min():.3e}")
+
+
+def main_seeded():
+    # (2) at SURVEY.md 8c's size: N = 4096, d = 512, nq = 4, k = 10 -- L2 and IP on normalised rows
+    emit_seeded("seeded_l2_n4096_d512_k10", "uniform", 20, 4096, 512, 4, 10, L2)
+    emit_seeded("seeded_ip_norm_n4096_d512_k10", "uniform_unit", 21, 4096, 512, 4, 10, IP)
+    # (8) at its size: 2048 x 128 descriptors against 256 unit-norm centroids, IP-argmax == L2-argmin
+    emit_seeded("seeded_assign_ip_n2048_c256_d128", "assign", 22, 256, 128, 2048, 1, IP)
+    emit_seeded("seeded_assign_l2_n2048_c256_d128", "assign", 22, 256, 128, 2048, 1, L2)
+
+
 if __name__ == "__main__":
-    main()
+    if "--seeded" in sys.argv:   # only the seeded fixtures (the stored ones above stay byte-identical)
+        main_seeded()
+    else:
+        main()
+        main_seeded()

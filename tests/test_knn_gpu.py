@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import knn_oracle as ko
-from tests.knn_checks import assert_knn_matches
+from tests.knn_checks import assert_knn_matches, load_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +38,7 @@ GOLDEN = [g for g in GOLDEN if not os.path.basename(g).startswith("normalize")]
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
 def test_golden_fixture(faiss, path):
-    z = np.load(path)
+    z = load_fixture(path)
     xb, xq, k, metric = z["xb"], z["xq"], int(z["k"]), int(z["metric"])
     index = make_index(faiss, metric, xb.shape[1])
     index.add(xb)

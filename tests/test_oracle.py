@@ -9,7 +9,7 @@ import pytest
 from oracle import flat_oracle as fo
 from oracle import knn_oracle as ko
 from tests import keycodec as kc
-from tests.knn_checks import assert_knn_matches
+from tests.knn_checks import assert_knn_matches, load_fixture
 
 L2, IP = ko.METRIC_L2, ko.METRIC_INNER_PRODUCT
 GOLDEN = sorted(g for g in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
@@ -18,14 +18,14 @@ GOLDEN = sorted(g for g in glob.glob(os.path.join(os.path.dirname(__file__), "go
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
 def test_numpy_oracle_reproduces_golden(path):
-    z = np.load(path)
+    z = load_fixture(path)
     D, I = ko.knn_exact(z["xb"], z["xq"], int(z["k"]), int(z["metric"]))
     assert np.array_equal(I, z["I"]) and np.array_equal(D, z["D"])
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
 def test_c_restatement_matches_golden(path):
-    z = np.load(path)
+    z = load_fixture(path)
     xb, xq, k, metric = z["xb"], z["xq"], int(z["k"]), int(z["metric"])
     for nthreads in (0, 3):  # Faiss's own per-query scheme, and the slab-split one
         D, I, _ = fo.knn_flat(xb, xq, k, metric, nthreads)
