@@ -72,6 +72,8 @@ struct ExactParams {
     uint32_t seq;
     unsigned long long* stats;  // [0] queries reranked, [1] queries sent to the exact scan
     int force_fail;    // test knob ($ISE_FORCE_EXACT=1): fail every certificate
+    // large-batch path: rows with lo > tau[q] never became candidates; the certificate covers them too
+    const float* tau_bound;  // [nq] or null
 };
 
 // append query q to the launch's fallback list (the counter is tagged with the launch sequence
@@ -207,6 +209,10 @@ __device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsign
         const float lo_last = unord_f32((uint32_t)(kin[p.kc - 1] >> 32));
         const float d_k = unord_f32((uint32_t)(kex[p.k - 1] >> 32));
         ok = lo_last > d_k;  // false on NaN
+    }
+    if (p.tau_bound) {  // rows cut by the admit threshold have lo > tau: tau >= d_(k) keeps them out of the top k
+        if (count >= p.k) ok = ok && p.tau_bound[q] >= unord_f32((uint32_t)(kex[p.k - 1] >> 32));
+        else ok = ok && (long long)count >= p.n;  // fewer than k candidates and rows left outside: not a result
     }
     if (p.force_fail) ok = false;
     for (int r = tid; r < p.k; r += NT) emit_exact(p, (size_t)q * p.k + r, r < count ? kex[r] : KEY_PAD);

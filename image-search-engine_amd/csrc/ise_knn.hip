@@ -34,6 +34,7 @@
 #include "ise_exact.hpp"
 #include "ise_merge.hpp"
 #include "ise_exact_scan.hpp"
+#include "ise_gemm_scan.hpp"
 #include "ise_rows.hpp"
 
 // ---------------------------------------------------------------- host side
@@ -80,6 +81,7 @@ struct ise_index {
     long long norms_rows = 0;  // rows whose norm is valid
     unsigned long long* stats_dev = nullptr;  // [4]: reranked queries, exact-scan queries
     unsigned long long mu_updates = 0;
+    unsigned long long gemm_chunks = 0;  // query chunks that took the large-batch path
     // workspaces (grown lazily, guarded by mu): NWS slots, so searches on different streams
     // may be in flight together.  A stream keeps the slot it used last (stream order is all
     // the ordering that needs); a stream without one takes a fresh slot, or the least
@@ -95,6 +97,9 @@ struct ise_index {
         u64* xchg = nullptr;      // threshold-exchange entries of the scan kernel, tagged by xchg_seq
         size_t xchg_elems = 0;
         uint32_t xchg_seq = 0;    // bumped per scan launch: entries of older launches never match
+        // large-batch path (ise_gemm_scan.hpp): one allocation holding qprep | xn | tau | ccnt | sample keys | cand
+        char* gemm = nullptr;
+        size_t gemm_bytes = 0;
         u64* fl_state = nullptr;  // exact path: launch seq << 32 | number of queries on the fallback list
         int* fl_list = nullptr;   // [fl_elems] the listed queries
         size_t fl_elems = 0;
@@ -225,6 +230,7 @@ static void free_all(ise_index* h) {
         if (w.part) (void)hipFree(w.part);
         if (w.keys_tmp) (void)hipFree(w.keys_tmp);
         if (w.xchg) (void)hipFree(w.xchg);
+        if (w.gemm) (void)hipFree(w.gemm);
         if (w.fl_state) (void)hipFree(w.fl_state);
         if (w.fl_list) (void)hipFree(w.fl_list);
         if (w.done) (void)hipEventDestroy(w.done);
@@ -515,6 +521,8 @@ struct ScanPlan {
     size_t lds;
     bool exact;  // float32 L2: the scan is the filter of the exact search (ise_exact.hpp)
     int kc;      // keys per query the scan + merge stage selects: k, or k + extra candidates when exact
+    bool gemm;   // the batch takes the large-batch path (ise_gemm_scan.hpp): the slot also holds its buffers
+    size_t gemm_bytes;
 };
 
 // candidates kept beyond k on the exact path: enough that the certificate holds on data whose
@@ -617,6 +625,8 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     pl->nblocks = (pl->tiles_total + pl->tiles_per_block - 1) / pl->tiles_per_block;
     if (pl->nblocks < 1) pl->nblocks = 1;
     pl->nqt = (int)((nq + 16 * pl->T - 1) / (16 * pl->T));
+    pl->gemm = false;
+    pl->gemm_bytes = 0;
     return ISE_OK;
 }
 
@@ -655,6 +665,17 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
             w->keys_tmp_elems = 0;
             HIP_TRY(hipMalloc(&w->keys_tmp, need2 * sizeof(u64)));
             w->keys_tmp_elems = need2;
+            *changed = true;
+        }
+    }
+    if (pl.gemm) {
+        const size_t needg = pl.gemm_bytes;
+        if (needg > w->gemm_bytes) {
+            if (w->gemm) (void)hipFree(w->gemm);
+            w->gemm = nullptr;
+            w->gemm_bytes = 0;
+            HIP_TRY(hipMalloc(&w->gemm, needg));
+            w->gemm_bytes = needg;
             *changed = true;
         }
     }
@@ -785,6 +806,147 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
     return ISE_OK;
 }
 
+// ---- large query batches against float32 L2 rows: sample pass (dump) -> thresholds -> GEMM-shaped
+// pass -> select + exact re-rank (ise_gemm_scan.hpp)
+#define GEMM_MIN_NQ 256
+#define GEMM_CAPQ 4096        /* candidate slots per query (a power of two); expected fill ~ N kc / sample rows */
+#define GEMM_SAMPLE_SLABS 128 /* 128-row slabs in the threshold sample (16384 rows), spread over the index */
+static bool gemm_applies(const ise_index* h, long long nq, int k) {
+    static const bool off = [] { const char* e = getenv("ISE_NO_GEMM"); return e && e[0] == '1'; }();
+    if (off || !uses_shift(h) || nq < GEMM_MIN_NQ) return false;
+    if (k + exact_extra(k) > KPASS_MAX) return false;            // the select stage hands one pass of candidates to the re-rank
+    if (h->dp > 512 || h->dp % 128 != 0) return false;            // the row tile lives in <= 128 VGPRs
+    return h->n >= 128ll * 1024;                                  // shorter indexes: the streaming passes are as fast
+}
+#define GEMM_CAPW 2048 /* entries of a wave's candidate buffer (expected fill: a few hundred) */
+struct GemmLayout {
+    size_t qprep, xn, tau, ccnt, dump, cand, wbuf, wcnt, total;
+};
+static GemmLayout gemm_layout(const ise_index* h) {
+    GemmLayout g;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    g.qprep = take((size_t)GEMM_NQ_MAX * qs_stride_for(h) * 4);
+    g.xn = take((size_t)GEMM_NQ_MAX * 4);
+    g.tau = take((size_t)GEMM_NQ_MAX * 4);
+    g.ccnt = take((size_t)(GEMM_NQ_MAX * GEMM_SUBS + 64) * 4);  // [GEMM_NQ_MAX][GEMM_SUBS] counters + the overflow flag
+    g.dump = take((size_t)GEMM_NQ_MAX * GEMM_SAMPLE_SLABS * 128 * 4);
+    g.cand = take((size_t)GEMM_NQ_MAX * GEMM_CAPQ * 8);
+    g.wbuf = take((size_t)h->num_cu * 8 * GEMM_CAPW * 16);
+    g.wcnt = take((size_t)h->num_cu * 8 * 4);
+    g.total = o;
+    return g;
+}
+
+// the plan a batch is enqueued with: large batches of float32 L2 queries go through the GEMM-shaped path
+// in chunks of GEMM_NQ_MAX, so their streaming plan (the exact fallback's shape, the slot's lists) is a chunk's
+static int plan_for_batch(const ise_index* h, long long nq, int k, ScanPlan* pl) {
+    const bool big = gemm_applies(h, nq, k);
+    int rc = make_plan(h, big ? std::min<long long>(nq, GEMM_NQ_MAX) : nq, k, pl);
+    if (rc) return rc;
+    pl->gemm = big;
+    pl->gemm_bytes = big ? gemm_layout(h).total : 0;
+    return ISE_OK;
+}
+
+template <int NS, bool DUMP>
+static void launch_gemm_one(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_scan_kernel<NS, DUMP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_scan_kernel<NS, DUMP>), dim3(grid), dim3(512), lds, st, gp);
+}
+template <bool DUMP>
+static int launch_gemm(int ns, int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
+    switch (ns) {
+        case 8: launch_gemm_one<8, DUMP>(grid, lds, st, gp); break;
+        case 16: launch_gemm_one<16, DUMP>(grid, lds, st, gp); break;
+        case 24: launch_gemm_one<24, DUMP>(grid, lds, st, gp); break;
+        case 32: launch_gemm_one<32, DUMP>(grid, lds, st, gp); break;
+        default: return fail(ISE_E_INVALID, "large-batch path: unsupported padded dimension");
+    }
+    return ISE_OK;
+}
+
+// one chunk of <= GEMM_NQ_MAX queries; the slot w is already this stream's
+static int search_large_chunk(ise_index* h, ise_index::WorkSlot* w, const float* q_dev, long long nq, int k,
+                              uint32_t id_base, float* D_dev, long long* I_dev, u64* keys_out, hipStream_t st,
+                              TimedOut* tm) {
+    const int kc = k + exact_extra(k);
+    const int S = qs_stride_for(h);
+    const GemmLayout gl = gemm_layout(h);
+    h->gemm_chunks++;
+    float* qprep = reinterpret_cast<float*>(w->gemm + gl.qprep);
+    float* xn = reinterpret_cast<float*>(w->gemm + gl.xn);
+    float* tau = reinterpret_cast<float*>(w->gemm + gl.tau);
+    unsigned int* ccnt = reinterpret_cast<unsigned int*>(w->gemm + gl.ccnt);
+    float* dump = reinterpret_cast<float*>(w->gemm + gl.dump);
+    u64* cand = reinterpret_cast<u64*>(w->gemm + gl.cand);
+    const int nq_pad = (int)((nq + GQ - 1) / GQ * GQ);
+    int rc;
+
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
+    hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, q_dev, (int)nq, nq_pad, h->d, S,
+                       (const float*)h->mu, qprep, xn);
+    HIP_TRY(hipGetLastError());
+
+    GemmScanParams gp;
+    gp.xb = (const float*)h->xb; gp.norms = h->norms; gp.mu = h->mu; gp.n = h->n; gp.rows16 = (h->n + 15) / 16 * 16;
+    gp.dp = h->dp; gp.S = S; gp.qprep = qprep; gp.xn = xn; gp.tau = tau; gp.nq = (int)nq; gp.nq_pad = nq_pad;
+    gp.beta = exact_beta(h); gp.id_base = id_base;
+    gp.wbuf = reinterpret_cast<u32x4*>(w->gemm + gl.wbuf); gp.wcnt = reinterpret_cast<unsigned int*>(w->gemm + gl.wcnt);
+    gp.capw = GEMM_CAPW;
+    const int slabs_all = (int)((h->n + 127) / 128);
+    const size_t lds = gemm_lds_bytes(S);
+    const int ns = h->dp / 16;
+
+    // ---- thresholds: GEMM_SAMPLE_SLABS slabs spread over the index, every score dumped, k-th selected per query.
+    // One slab per block, the query stages split over qparts blocks per slab, so that the sample
+    // keeps every CU busy for a fraction of a slab's time.
+    gp.slabs = std::min(slabs_all, GEMM_SAMPLE_SLABS);
+    gp.slab_stride = slabs_all / gp.slabs;
+    const int nstages = nq_pad / GQ;
+    gp.qparts = std::max(1, std::min(nstages, (2 * h->num_cu) / gp.slabs));
+    gp.dump = dump;
+    if ((rc = launch_gemm<true>(ns, gp.slabs * gp.qparts, lds, st, gp))) return rc;
+    hipLaunchKernelGGL(kth_select_kernel, dim3((unsigned)nq_pad), dim3(256), 0, st, (const float*)dump, gp.slabs * 128, kc,
+                       (int)nq, tau);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(GEMM_NQ_MAX * GEMM_SUBS + 64) * 4, st));  // the counters and, behind them, the overflow flag
+
+    // ---- the GEMM-shaped pass over the whole index
+    gp.slabs = slabs_all; gp.slab_stride = 1; gp.qparts = 1; gp.dump = nullptr;
+    const int grid = std::min(slabs_all, h->num_cu);
+    if ((rc = launch_gemm<false>(ns, grid, lds, st, gp))) return rc;
+    unsigned int* overflow = ccnt + GEMM_NQ_MAX * GEMM_SUBS;
+    hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)grid * 8), dim3(256), 0, st, (const u32x4*)gp.wbuf,
+                       (const unsigned int*)gp.wcnt, GEMM_CAPW, cand, ccnt, GEMM_CAPQ, overflow);
+    HIP_TRY(hipGetLastError());
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
+
+    // ---- select the kc best candidates, re-rank exactly, certify; the exact scan takes what fails
+    ScanPlan pl;  // shapes the exact fallback scan (blocks, rows per block) and sized the slot's lists
+    rc = make_plan(h, nq, k, &pl);
+    if (rc) return rc;
+    ExactParams xp;
+    xp.xb = (const float*)h->xb; xp.q = q_dev; xp.n = h->n; xp.d = h->d; xp.dp = h->dp; xp.nq = (int)nq;
+    xp.k = k; xp.kc = kc; xp.id_base = id_base; xp.D = D_dev; xp.I = I_dev; xp.keys_out = keys_out;
+    xp.fl_state = w->fl_state; xp.fl_list = w->fl_list; xp.seq = 0; xp.stats = h->stats_dev;
+    xp.force_fail = force_exact() ? 1 : 0;
+    xp.tau_bound = tau;
+    if ((rc = next_fl_seq(w, st, &xp.seq))) return rc;
+    hipLaunchKernelGGL(gemm_select_kernel, dim3((unsigned)nq), dim3(256),
+                       rerank_lds_bytes(h->dp, kc) + (size_t)GEMM_CAPQ * 8, st, xp, (const u64*)cand,
+                       (const unsigned int*)ccnt, GEMM_CAPQ, (const unsigned int*)overflow);
+    HIP_TRY(hipGetLastError());
+    if ((rc = enqueue_exact_fallback(h, w, pl, xp, nq, st))) return rc;
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e2, st));
+    return ISE_OK;
+}
+
 // enqueue one search batch; outputs (D, I) and/or keys.  Nothing here blocks once the slots are
 // sized (first batch of a shape) and the shift is current (first batch after rows were added).
 static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k, uint32_t id_base, float* D_dev,
@@ -792,9 +954,9 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     int rc = prepare_shift_locked(h, st);
     if (rc) return rc;
     ScanPlan pl;
-    rc = make_plan(h, nq, k, &pl);
+    rc = plan_for_batch(h, nq, k, &pl);
     if (rc) return rc;
-    rc = ensure_workspaces(h, pl, nq);
+    rc = ensure_workspaces(h, pl, pl.gemm ? std::min<long long>(nq, GEMM_NQ_MAX) : nq);
     if (rc) return rc;
     ise_index::WorkSlot* w = nullptr;
     bool same_stream = false;
@@ -812,6 +974,17 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
             if (hipEventRecord(w->done, st) == hipSuccess) { w->used = true; w->last_stream = st; }
         }
     } release{w, st};
+
+    if (pl.gemm) {  // float32 L2, nq >= 64: GEMM-shaped filter pass, GEMM_NQ_MAX queries at a time
+        for (long long q0 = 0; q0 < nq; q0 += GEMM_NQ_MAX) {
+            const long long m = std::min<long long>(GEMM_NQ_MAX, nq - q0);
+            rc = search_large_chunk(h, w, q_dev + (size_t)q0 * h->d, m, k, id_base, D_dev ? D_dev + (size_t)q0 * k : nullptr,
+                                    I_dev ? I_dev + (size_t)q0 * k : nullptr, keys_out ? keys_out + (size_t)q0 * k : nullptr,
+                                    st, tm);
+            if (rc) return rc;
+        }
+        return ISE_OK;
+    }
 
     ScanParams sp;
     sp.xb = h->xb; sp.norms = h->norms; sp.q = q_dev; sp.mu = h->mu; sp.floor_keys = nullptr; sp.part = w->part;
@@ -842,6 +1015,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     xp.k = k; xp.kc = pl.kc; xp.id_base = id_base; xp.D = D_dev; xp.I = I_dev; xp.keys_out = keys_out;
     xp.fl_state = w->fl_state; xp.fl_list = w->fl_list; xp.seq = 0; xp.stats = h->stats_dev;
     xp.force_fail = force_exact() ? 1 : 0;
+    xp.tau_bound = nullptr;
 
     const dim3 grid((unsigned)pl.nblocks, (unsigned)pl.nqt);
     if (pl.kc <= pl.kpass) {  // one scan pass selects everything the merge stage needs
@@ -1041,9 +1215,9 @@ extern "C" int ise_index_reserve_workspaces(ise_index_t* h, int64_t nq, int k) {
     rc = prepare_shift_locked(h, h->stream);
     if (rc) return rc;
     ScanPlan pl;
-    rc = make_plan(h, nq, k, &pl);
+    rc = plan_for_batch(h, nq, k, &pl);
     if (rc) return rc;
-    return ensure_workspaces(h, pl, nq);
+    return ensure_workspaces(h, pl, pl.gemm ? std::min<long long>(nq, GEMM_NQ_MAX) : nq);
 }
 
 extern "C" int ise_index_stats(ise_index_t* h, uint64_t* out4) {
@@ -1066,7 +1240,7 @@ extern "C" int ise_index_stats(ise_index_t* h, uint64_t* out4) {
     out4[0] = tmp[0];
     out4[1] = tmp[1];
     out4[2] = h->mu_updates;
-    out4[3] = 0;
+    out4[3] = h->gemm_chunks;
     return ISE_OK;
 }
 

@@ -97,7 +97,8 @@ class IndexFlat:
         shift vector."""
         out = (ctypes.c_uint64 * 4)()
         _n.check(_n.lib.ise_index_stats(self._h, out))
-        return {"reranked": int(out[0]), "exact_scan": int(out[1]), "shift_updates": int(out[2])}
+        return {"reranked": int(out[0]), "exact_scan": int(out[1]), "shift_updates": int(out[2]),
+                "gemm_chunks": int(out[3])}
 
     def reserve(self, nq: int, k: int) -> None:
         """Size every internal workspace for batches of ``nq`` queries / ``k`` results now, so that the

@@ -91,7 +91,8 @@ int ise_index_get_shift(ise_index_t* h, float* mu_host);
 
 /* Counters of the exact float32 L2 path since the index was created:
  *   out4[0] queries re-ranked, out4[1] queries whose certificate failed and that were recomputed by
- *   the exact scan, out4[2] refreshes of the shift vector, out4[3] reserved (0).  Blocks. */
+ *   the exact scan, out4[2] refreshes of the shift vector, out4[3] query chunks (<= 1024 queries) that
+ *   took the large-batch GEMM-shaped path (nq >= 64).  Blocks. */
 int ise_index_stats(ise_index_t* h, uint64_t* out4);
 
 /* Size every internal workspace for batches of nq queries and k results now (device allocations,

@@ -315,3 +315,59 @@ def test_concurrent_host_searches_overlap_and_agree(faiss):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errors, errors
+
+
+# ---------------------------------------------------------------- large batches: the GEMM-shaped path
+@pytest.mark.parametrize("d,nq,k", [(512, 256, 10), (512, 300, 20), (128, 1024, 10), (256, 333, 1), (384, 260, 28)])
+def test_large_batch_gemm_path_matches_oracle(faiss, d, nq, k):
+    """nq >= 256 against a float32 L2 index of >= 128k rows: strided-sample thresholds, one GEMM-shaped
+    pass, candidate select, exact re-rank (csrc/ise_gemm_scan.hpp).  Same answers as the oracle and as
+    the streaming path (bit for bit: both end in the same direct-difference re-rank)."""
+    from oracle import flat_oracle as fo
+
+    rng = np.random.default_rng(d + nq + k)
+    n = 140_000
+    xb = rng.random((n, d), dtype=np.float32)
+    xq = rng.random((nq, d), dtype=np.float32)
+    xq[3] = xb[77]                      # an exact hit
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    before = index.exact_stats()
+    D, I = index.search(xq, k)
+    after = index.exact_stats()
+    assert after["gemm_chunks"] == before["gemm_chunks"] + 1, "the batch did not take the large-batch path"
+    assert after["exact_scan"] == before["exact_scan"], "certificate failed on uniform data"
+    Dr, Ir, _ = fo.knn_flat(xb, xq, k, 1, 16)
+    assert_knn_matches(D, I, Dr, Ir, xb, xq, L2, atol=ATOL_UNIFORM)
+    assert I[3, 0] == 77 and D[3, 0] == 0.0
+    # the streaming path on the same queries (batches below 256 queries): identical bits
+    Ds = np.concatenate([index.search(xq[i:i + 48], k)[0] for i in range(0, nq, 48)])
+    Is = np.concatenate([index.search(xq[i:i + 48], k)[1] for i in range(0, nq, 48)])
+    assert np.array_equal(Is, I) and np.array_equal(Ds, D)
+    with forced_exact():
+        Df, If = index.search(xq, k)
+    assert np.array_equal(If, I) and np.array_equal(Df, D)
+
+
+def test_large_batch_gemm_path_on_cluster_sorted_rows(faiss):
+    """Rows sorted by cluster, queries near every cluster: the strided sample still sees every cluster,
+    thresholds stay tight, nothing overflows; and far-apart clusters go through the exact scan."""
+    rng = np.random.default_rng(31)
+    n, d, nq, k = 160_000, 128, 288, 10
+    xb = _adversarial("cluster_sorted", rng, n, d)
+    xq = (xb[rng.integers(0, n, nq)] + 0.03 * rng.standard_normal((nq, d))).astype(np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    assert index.exact_stats()["gemm_chunks"] == 1
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2, gap=ko.kth_gap(xb, xq, k, L2))
+    xb2 = _adversarial("two_far_clusters", rng, n, d)
+    xq2 = (xb2[rng.integers(0, n, 256)] + 0.03 * rng.standard_normal((256, d))).astype(np.float32)
+    index2 = faiss.IndexFlatL2(d)
+    index2.add(xb2)
+    D2, I2 = index2.search(xq2, k)
+    st = index2.exact_stats()
+    assert st["gemm_chunks"] == 1 and st["exact_scan"] > 0
+    D_ref, I_ref = ko.knn_exact(xb2, xq2, k, L2)
+    assert_knn_matches(D2, I2, D_ref, I_ref, xb2, xq2, L2, gap=ko.kth_gap(xb2, xq2, k, L2))
