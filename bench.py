@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak, same guide
 
 
 def make_inputs(n, d, nq, lo, hi):
@@ -258,9 +259,12 @@ def main():
     # roofline of the dominant kernel (the shard-local scan), timed with HIP events on
     # the stream it runs on, inside the library
     n_local = hi - lo
-    _, _, scan_ms, merge_ms = local.search_timed_torch(xq, k, 50)
+    _, _, scan_ms, merge_ms = local.search_timed_torch(xq, k, 50 if nq <= 64 else 10)
     alg_bytes = 4.0 * n_local * d + 4.0 * nq * d + 12.0 * nq * k
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
+    # batches of >= 256 queries take the GEMM-shaped pass (csrc/ise_gemm_scan.hpp): MFMA-bound, priced in flops
+    gemm_batch = local.exact_stats().get("gemm_chunks", 0) > 0
+    alg_flops = 2.0 * nq * n_local * d
 
     # per-batch latency (median + p10/p90): one batch at a time on one stream, an
     # event pair around scan + merge.  Single-GPU runs only; the timed region above is the metric.
@@ -299,10 +303,16 @@ def main():
                                    + f"; {CLOCK_WARMUP_STEPS} untimed steps ahead of the warm-up bring the GPU out of "
                                      f"its idle power state",
                        "n": n, "d": d, "k": k, "nq": nq},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, d, nq, k, world),
-                         "kernel": "scan_kernel", "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
-                         "algorithmic_bytes": alg_bytes,
+            "roofline": {"bound": "mfma" if gemm_batch else "hbm",
+                         "achieved": alg_flops / (scan_ms * 1e-3) / 1e12 if gemm_batch else achieved,
+                         "peak": MFMA_F32_PEAK_TF if gemm_batch else HBM_PEAK_GBS,
+                         "unit": "TFLOP/s" if gemm_batch else "GB/s",
+                         "frac": (alg_flops / (scan_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF) if gemm_batch
+                         else achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(n, d, nq, k, world),
+                         "kernel": "gemm_scan_kernel (threshold sample + main pass)" if gemm_batch else "scan_kernel",
+                         "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
+                         "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
                          # the same bytes over the measured step time (batches overlapped on the GPU):
                          # what the whole step sustains, beside the isolated kernel's figure above
                          "step_effective": {"achieved": alg_bytes / (el / args.steps) / 1e9,
