@@ -297,8 +297,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{n}x{d} fp32 uniform[0,1) index (default_rng 1234), L2, k={k}, "
                                    f"nq={nq} queries per step, index resident in HBM, "
-                                   + (f"row-sharded over {world} GPUs, one all-gather + merge per {depth} steps, "
-                                      f"4 buckets (streams) in flight" if sharded else
+                                   + (f"row-sharded over {world} GPUs, one all-gather ({index.collective}) + merge per {depth} "
+                                      f"steps, 4 buckets (streams) in flight" if sharded else
                                       f"steps issued round-robin on {n_streams} HIP streams")
                                    + f"; {CLOCK_WARMUP_STEPS} untimed steps ahead of the warm-up bring the GPU out of "
                                      f"its idle power state",
@@ -360,6 +360,10 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if sharded:
+        if index.comm is not None:  # the library's communicator goes before the process group that bootstrapped it
+            torch.cuda.synchronize()
+            barrier()
+            index.comm.close()
         dist.destroy_process_group()
 
 
