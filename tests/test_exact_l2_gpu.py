@@ -371,3 +371,44 @@ def test_large_batch_gemm_path_on_cluster_sorted_rows(faiss):
     assert st["gemm_chunks"] == 1 and st["exact_scan"] > 0
     D_ref, I_ref = ko.knn_exact(xb2, xq2, k, L2)
     assert_knn_matches(D2, I2, D_ref, I_ref, xb2, xq2, L2, gap=ko.kth_gap(xb2, xq2, k, L2))
+
+
+def test_large_batch_path_on_concurrent_streams_and_threads(faiss):
+    """The GEMM-shaped path keeps its buffers per workspace slot: batches of different sizes issued
+    from several host threads on their own streams (and interleaved with small batches) stay correct
+    and bitwise reproducible."""
+    import threading
+
+    import torch
+    from oracle import flat_oracle as fo
+
+    rng = np.random.default_rng(41)
+    n, d, k = 150_000, 128, 10
+    xb = rng.random((n, d), dtype=np.float32)
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    qs = [rng.random((nq, d), dtype=np.float32) for nq in (256, 16, 700, 1100, 300)]
+    refs = [fo.knn_flat(xb, q, k, 1, 8)[:2] for q in qs]
+    errors = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            tq = torch.from_numpy(qs[i]).cuda()
+            torch.cuda.synchronize()
+            outs = []
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    outs.append(index.search_torch(tq, k))
+            st.synchronize()
+            assert_knn_matches(outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy(), refs[i][0], refs[i][1], xb, qs[i], L2,
+                               atol=ATOL_UNIFORM)
+            assert all(torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][0], o[0]) for o in outs)
+        except Exception as e:  # surfaced in the main thread
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(qs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert index.exact_stats()["gemm_chunks"] >= 6 * 5  # 256, 700, 1100 (two chunks) and 300 queries, six times each
