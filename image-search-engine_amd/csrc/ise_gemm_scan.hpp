@@ -50,6 +50,7 @@ struct GemmScanParams {
     const float* tau;     // [nq_pad] admit score per query (+FLT_MAX admits everything finite)
     int nq, nq_pad;       // nq_pad: multiple of GQ, <= GEMM_NQ_MAX
     float beta;
+    int metric;           // bf16 rows only (ise_gemm_bf16.hpp); the float32 kernel is L2
     uint32_t id_base;
     // candidates leave the GEMM pass without atomics: every wave appends (key, query) entries to a
     // buffer of its own; regroup_kernel sorts them out per query afterwards

@@ -35,6 +35,7 @@
 #include "ise_merge.hpp"
 #include "ise_exact_scan.hpp"
 #include "ise_gemm_scan.hpp"
+#include "ise_gemm_bf16.hpp"
 #include "ise_rows.hpp"
 
 // ---------------------------------------------------------------- host side
@@ -780,7 +781,7 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
     const size_t lds = (size_t)XQ * h->dp * 4 + (size_t)XQ * 4 * 32 * 8;
     MergeParams mp;  // the per-block lists are merged by the scan's last block
     mp.lists = w->part; mp.qt = 1; mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.metric = h->metric;
-    mp.fl_state = w->fl_state; mp.fl_list = w->fl_list; mp.seq = xp.seq; mp.dbg = nullptr;
+    mp.fl_state = w->fl_state; mp.fl_list = w->fl_list; mp.seq = xp.seq; mp.dbg = nullptr; mp.gate = nullptr;
     const int k = xp.k;
     if (k <= KPASS_MAX) {
         xs.kpass = k; xs.floor_keys = nullptr;
@@ -813,10 +814,11 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
 #define GEMM_SAMPLE_SLABS 128 /* 128-row slabs in the threshold sample (16384 rows), spread over the index */
 static bool gemm_applies(const ise_index* h, long long nq, int k) {
     static const bool off = [] { const char* e = getenv("ISE_NO_GEMM"); return e && e[0] == '1'; }();
-    if (off || !uses_shift(h) || nq < GEMM_MIN_NQ) return false;
-    if (k + exact_extra(k) > KPASS_MAX) return false;            // the select stage hands one pass of candidates to the re-rank
-    if (h->dp > 512 || h->dp % 128 != 0) return false;            // the row tile lives in <= 128 VGPRs
-    return h->n >= 128ll * 1024;                                  // shorter indexes: the streaming passes are as fast
+    if (off || nq < GEMM_MIN_NQ || h->n < 128ll * 1024) return false;  // shorter indexes: the streaming passes are as fast
+    if (h->dp > 512 || h->dp % 128 != 0) return false;            // the row tiles live in <= 128 VGPRs
+    if (h->storage == ISE_STORE_BF16) return k <= KPASS_MAX;      // either metric (ise_gemm_bf16.hpp)
+    if (!uses_shift(h)) return false;                             // float32 inner product: the streaming passes
+    return k + exact_extra(k) <= KPASS_MAX;                       // the select stage hands one pass of candidates to the re-rank
 }
 #define GEMM_CAPW 2048 /* entries of a wave's candidate buffer (expected fill: a few hundred) */
 struct GemmLayout {
@@ -947,45 +949,14 @@ static int search_large_chunk(ise_index* h, ise_index::WorkSlot* w, const float*
     return ISE_OK;
 }
 
-// enqueue one search batch; outputs (D, I) and/or keys.  Nothing here blocks once the slots are
-// sized (first batch of a shape) and the shift is current (first batch after rows were added).
-static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k, uint32_t id_base, float* D_dev,
-                          long long* I_dev, u64* keys_out, hipStream_t st, TimedOut* tm) {
-    int rc = prepare_shift_locked(h, st);
-    if (rc) return rc;
-    ScanPlan pl;
-    rc = plan_for_batch(h, nq, k, &pl);
-    if (rc) return rc;
-    rc = ensure_workspaces(h, pl, pl.gemm ? std::min<long long>(nq, GEMM_NQ_MAX) : nq);
-    if (rc) return rc;
-    ise_index::WorkSlot* w = nullptr;
-    bool same_stream = false;
-    for (auto& s : h->ws)
-        if (s.used && s.last_stream == st) { w = &s; same_stream = true; break; }
-    if (!w)
-        for (auto& s : h->ws)
-            if (!s.used) { w = &s; break; }
-    if (!w) w = &h->ws[h->ws_next++ % ise_index::NWS];
-    if (w->used && !same_stream) HIP_TRY(hipStreamWaitEvent(st, w->done, 0));
-    struct Release {  // whatever path returns, a later user on another stream waits for this call
-        ise_index::WorkSlot* w;
-        hipStream_t st;
-        ~Release() {
-            if (hipEventRecord(w->done, st) == hipSuccess) { w->used = true; w->last_stream = st; }
-        }
-    } release{w, st};
-
-    if (pl.gemm) {  // float32 L2, nq >= 64: GEMM-shaped filter pass, GEMM_NQ_MAX queries at a time
-        for (long long q0 = 0; q0 < nq; q0 += GEMM_NQ_MAX) {
-            const long long m = std::min<long long>(GEMM_NQ_MAX, nq - q0);
-            rc = search_large_chunk(h, w, q_dev + (size_t)q0 * h->d, m, k, id_base, D_dev ? D_dev + (size_t)q0 * k : nullptr,
-                                    I_dev ? I_dev + (size_t)q0 * k : nullptr, keys_out ? keys_out + (size_t)q0 * k : nullptr,
-                                    st, tm);
-            if (rc) return rc;
-        }
-        return ISE_OK;
-    }
-
+// The streaming path for one batch on slot w: scan pass(es) -> merge (-> exact re-rank -> gated exact scan
+// for float32 L2).  gate: optional device flag -- when given, every kernel of the batch exits at once
+// unless it is non-zero (the bf16 large-batch path queues this behind itself for the case that its
+// candidate buffers overflow).
+static int scan_path_enqueue(ise_index* h, ise_index::WorkSlot* w, const ScanPlan& pl, const float* q_dev, long long nq,
+                             int k, uint32_t id_base, float* D_dev, long long* I_dev, u64* keys_out, hipStream_t st,
+                             TimedOut* tm, const unsigned int* gate) {
+    int rc;
     ScanParams sp;
     sp.xb = h->xb; sp.norms = h->norms; sp.q = q_dev; sp.mu = h->mu; sp.floor_keys = nullptr; sp.part = w->part;
     sp.n = h->n; sp.d = h->d; sp.dp = h->dp; sp.qs_stride = qs_stride_for(h);
@@ -995,6 +966,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     sp.tiles_total = pl.tiles_total; sp.tiles_per_block = pl.tiles_per_block;
     sp.xchg = xchg_enabled() ? w->xchg : nullptr;
     sp.xchg_seq = 0;
+    sp.gate = gate;
     sp.ablate = 0;
     sp.stamps = nullptr;
 #ifdef ISE_ABLATE
@@ -1009,6 +981,7 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.k = pl.kpass; mp.metric = h->metric;
     mp.fl_state = nullptr; mp.fl_list = nullptr; mp.seq = 0; mp.out_by_pos = 0;
     mp.dbg = h->stats_dev + 8;
+    mp.gate = gate;
 
     ExactParams xp;  // used on the exact path only
     xp.xb = (const float*)h->xb; xp.q = q_dev; xp.n = h->n; xp.d = h->d; xp.dp = h->dp; xp.nq = (int)nq;
@@ -1075,6 +1048,138 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     }
     if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e2, st));
     return ISE_OK;
+}
+
+
+template <int NS, bool DUMP>
+static void launch_gemm_bf16_one(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_scan_bf16_kernel<NS, DUMP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_scan_bf16_kernel<NS, DUMP>), dim3(grid), dim3(512), lds, st, gp);
+}
+template <bool DUMP>
+static int launch_gemm_bf16(int ns, int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
+    switch (ns) {
+        case 4: launch_gemm_bf16_one<4, DUMP>(grid, lds, st, gp); break;
+        case 8: launch_gemm_bf16_one<8, DUMP>(grid, lds, st, gp); break;
+        case 12: launch_gemm_bf16_one<12, DUMP>(grid, lds, st, gp); break;
+        case 16: launch_gemm_bf16_one<16, DUMP>(grid, lds, st, gp); break;
+        default: return fail(ISE_E_INVALID, "large-batch path: unsupported padded dimension");
+    }
+    return ISE_OK;
+}
+
+// bf16 rows, one chunk of <= GEMM_NQ_MAX queries (ise_gemm_bf16.hpp): sample dump -> thresholds -> GEMM pass ->
+// regroup -> select; then the streaming passes, gated on the rerun flag (set when a candidate buffer overflowed)
+static int search_large_chunk_bf16(ise_index* h, ise_index::WorkSlot* w, const float* q_dev, long long nq, int k,
+                                   uint32_t id_base, float* D_dev, long long* I_dev, u64* keys_out, hipStream_t st,
+                                   TimedOut* tm) {
+    const int S = qs_stride_for(h);
+    const GemmLayout gl = gemm_layout(h);
+    h->gemm_chunks++;
+    uint32_t* qprep = reinterpret_cast<uint32_t*>(w->gemm + gl.qprep);
+    float* xn = reinterpret_cast<float*>(w->gemm + gl.xn);
+    float* tau = reinterpret_cast<float*>(w->gemm + gl.tau);
+    unsigned int* ccnt = reinterpret_cast<unsigned int*>(w->gemm + gl.ccnt);
+    float* dump = reinterpret_cast<float*>(w->gemm + gl.dump);
+    u64* cand = reinterpret_cast<u64*>(w->gemm + gl.cand);
+    const int nq_pad = (int)((nq + GQ - 1) / GQ * GQ);
+    int rc;
+
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
+    hipLaunchKernelGGL(qprep_bf16_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, q_dev, (int)nq, nq_pad, h->d, S,
+                       qprep, xn);
+    HIP_TRY(hipGetLastError());
+
+    constexpr int ROWS = 8 * GB_XT * 16;
+    GemmScanParams gp;
+    gp.xb = (const float*)h->xb; gp.norms = h->norms; gp.mu = nullptr; gp.n = h->n; gp.rows16 = (h->n + 15) / 16 * 16;
+    gp.dp = h->dp; gp.S = S; gp.qprep = reinterpret_cast<const float*>(qprep); gp.xn = xn; gp.tau = tau; gp.nq = (int)nq;
+    gp.nq_pad = nq_pad; gp.beta = 0.f; gp.metric = h->metric; gp.id_base = id_base;
+    gp.wbuf = reinterpret_cast<u32x4*>(w->gemm + gl.wbuf); gp.wcnt = reinterpret_cast<unsigned int*>(w->gemm + gl.wcnt);
+    gp.capw = GEMM_CAPW;
+    const int slabs_all = (int)((h->n + ROWS - 1) / ROWS);
+    const size_t lds = (size_t)2 * GQ * S * 4 + (size_t)2 * GEMM_NQ_MAX * 4;
+    const int ns = h->dp / 32;
+
+    gp.slabs = std::min(slabs_all, GEMM_SAMPLE_SLABS * 128 / ROWS);  // the same 16384 sample rows
+    gp.slab_stride = slabs_all / gp.slabs;
+    const int nstages = nq_pad / GQ;
+    gp.qparts = std::max(1, std::min(nstages, (2 * h->num_cu) / gp.slabs));
+    gp.dump = dump;
+    if ((rc = launch_gemm_bf16<true>(ns, gp.slabs * gp.qparts, lds, st, gp))) return rc;
+    hipLaunchKernelGGL(kth_select_kernel, dim3((unsigned)nq_pad), dim3(256), 0, st, (const float*)dump, gp.slabs * ROWS, k,
+                       (int)nq, tau);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(GEMM_NQ_MAX * GEMM_SUBS + 64) * 4, st));  // counters, overflow flag, rerun flag
+
+    gp.slabs = slabs_all; gp.slab_stride = 1; gp.qparts = 1; gp.dump = nullptr;
+    const int grid = std::min(slabs_all, h->num_cu);
+    if ((rc = launch_gemm_bf16<false>(ns, grid, lds, st, gp))) return rc;
+    unsigned int* overflow = ccnt + GEMM_NQ_MAX * GEMM_SUBS;
+    unsigned int* rerun = overflow + 1;
+    hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)grid * 8), dim3(256), 0, st, (const u32x4*)gp.wbuf,
+                       (const unsigned int*)gp.wcnt, GEMM_CAPW, cand, ccnt, GEMM_CAPQ, overflow);
+    HIP_TRY(hipGetLastError());
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
+    hipLaunchKernelGGL(gemm_select_plain_kernel, dim3((unsigned)nq), dim3(256), (size_t)GEMM_CAPQ * 8, st, (const u64*)cand,
+                       (const unsigned int*)ccnt, GEMM_CAPQ, (const unsigned int*)overflow, rerun, k, h->metric, D_dev, I_dev,
+                       keys_out);
+    HIP_TRY(hipGetLastError());
+    // incomplete candidates anywhere in the chunk: the streaming passes answer the whole chunk instead
+    ScanPlan pl;
+    rc = make_plan(h, nq, k, &pl);
+    if (rc) return rc;
+    rc = scan_path_enqueue(h, w, pl, q_dev, nq, k, id_base, D_dev, I_dev, keys_out, st, nullptr, rerun);
+    if (rc) return rc;
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e2, st));
+    return ISE_OK;
+}
+
+// enqueue one search batch; outputs (D, I) and/or keys.  Nothing here blocks once the slots are
+// sized (first batch of a shape) and the shift is current (first batch after rows were added).
+static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k, uint32_t id_base, float* D_dev,
+                          long long* I_dev, u64* keys_out, hipStream_t st, TimedOut* tm) {
+    int rc = prepare_shift_locked(h, st);
+    if (rc) return rc;
+    ScanPlan pl;
+    rc = plan_for_batch(h, nq, k, &pl);
+    if (rc) return rc;
+    rc = ensure_workspaces(h, pl, pl.gemm ? std::min<long long>(nq, GEMM_NQ_MAX) : nq);
+    if (rc) return rc;
+    ise_index::WorkSlot* w = nullptr;
+    bool same_stream = false;
+    for (auto& s : h->ws)
+        if (s.used && s.last_stream == st) { w = &s; same_stream = true; break; }
+    if (!w)
+        for (auto& s : h->ws)
+            if (!s.used) { w = &s; break; }
+    if (!w) w = &h->ws[h->ws_next++ % ise_index::NWS];
+    if (w->used && !same_stream) HIP_TRY(hipStreamWaitEvent(st, w->done, 0));
+    struct Release {  // whatever path returns, a later user on another stream waits for this call
+        ise_index::WorkSlot* w;
+        hipStream_t st;
+        ~Release() {
+            if (hipEventRecord(w->done, st) == hipSuccess) { w->used = true; w->last_stream = st; }
+        }
+    } release{w, st};
+
+    if (pl.gemm) {  // float32 L2 or bf16 rows, nq >= 256: GEMM-shaped pass, GEMM_NQ_MAX queries at a time
+        for (long long q0 = 0; q0 < nq; q0 += GEMM_NQ_MAX) {
+            const long long m = std::min<long long>(GEMM_NQ_MAX, nq - q0);
+            rc = (h->storage == ISE_STORE_BF16 ? search_large_chunk_bf16 : search_large_chunk)(
+                h, w, q_dev + (size_t)q0 * h->d, m, k, id_base, D_dev ? D_dev + (size_t)q0 * k : nullptr,
+                I_dev ? I_dev + (size_t)q0 * k : nullptr, keys_out ? keys_out + (size_t)q0 * k : nullptr, st, tm);
+            if (rc) return rc;
+        }
+        return ISE_OK;
+    }
+
+    return scan_path_enqueue(h, w, pl, q_dev, nq, k, id_base, D_dev, I_dev, keys_out, st, tm, nullptr);
 }
 
 static int check_search_args(const ise_index* h, const void* q, long long nq, int k) {
@@ -1327,7 +1432,7 @@ extern "C" int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int6
     mp.stride_qtile = (long long)k; mp.qt = 1;
     mp.n_lists = n_lists; mp.nq = (int)nq; mp.k = k; mp.metric = metric;
     mp.D = D_dev; mp.I = (long long*)I_dev; mp.keys_out = nullptr;
-    mp.fl_state = nullptr; mp.fl_list = nullptr; mp.seq = 0; mp.out_by_pos = 0; mp.dbg = nullptr;
+    mp.fl_state = nullptr; mp.fl_list = nullptr; mp.seq = 0; mp.out_by_pos = 0; mp.dbg = nullptr; mp.gate = nullptr;
     if (n_lists <= 64)
         hipLaunchKernelGGL(merge_small_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mp);
     else

@@ -24,6 +24,7 @@ struct MergeParams {
     uint32_t seq;
     int out_by_pos;
     unsigned long long* dbg;  // dev builds: stamp buffer or null
+    const unsigned int* gate;  // optional: the launch does nothing unless *gate != 0
 };
 
 __device__ __forceinline__ void emit_result(const MergeParams& p, size_t o, u64 key) {
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
     __shared__ MergeFastScratch fast;
     __shared__ u64 res[MERGE_FAST_K];
     extern __shared__ __align__(16) unsigned char smem_mr[];  // RERANK only: rerank_lds_bytes(dp, kc)
+    if (p.gate && *p.gate == 0u) return;
     int q = blockIdx.x, lq = blockIdx.x;
     if (p.fl_state) {
         const u64 st = __hip_atomic_load(p.fl_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

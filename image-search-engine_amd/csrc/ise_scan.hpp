@@ -59,6 +59,7 @@
 template <int CH, int W, int T, bool BF16, bool SHIFT>
 __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) void scan_kernel(const ScanParams p) {
     static_assert(!(BF16 && SHIFT), "the shift is applied to fp32 rows only");
+    if (p.gate && *p.gate == 0u) return;  // a queued rerun that is not needed
     constexpr int BLOCK_THREADS = W * 64;
     // threshold exchange: compiled into the 8-wave kernels with two or more query tiles, where the candidate
     // bookkeeping is what it saves (nq = 48: 560 -> 508 us; nq = 32: 399 (16 waves) -> 383 us).  Not into the

@@ -24,6 +24,7 @@ struct ScanParams {
     // block's best boot row); null = off.  See scan_kernel.
     unsigned long long* xchg;
     uint32_t xchg_seq;
+    const unsigned int* gate;  // optional: the launch does nothing unless *gate != 0 (queued reruns, ise_gemm_bf16.hpp)
     int ablate;  // dev builds (-DISE_ABLATE): bit mask of phases to skip, from $ISE_ABLATE
     unsigned long long* stamps;  // dev builds: [blocks][waves][16] stamps (0-7 s_memrealtime 100 MHz, 8-9 s_memtime), or null
 };

@@ -8,7 +8,8 @@ if len(sys.argv) > 1:
     n, d, k = int(os.environ.get("N", "1000000")), int(os.environ.get("D", "512")), 10
     g = torch.Generator(device="cuda").manual_seed(1)
     xb = torch.rand((n, d), generator=g, device="cuda")
-    index = faiss.IndexFlatL2(d); index.add_torch(xb)
+    storage = os.environ.get("STORAGE", "f32")
+    index = faiss.IndexFlat(d, 0 if storage == "bf16" else 1, storage=storage); index.add_torch(xb)
     out = []
     for nq in [int(x) for x in os.environ.get("NQS", "64,128,256,1024,4096").split(",")]:
         xq = torch.rand((nq, d), generator=g, device="cuda")
@@ -18,7 +19,7 @@ if len(sys.argv) > 1:
         for _ in range(reps): index.search_torch(xq, k)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
         out.append((nq, round(dt * 1e3, 3), round(nq / dt / 1e3, 1), round(2.0 * nq * n * d / dt / 1e12, 1)))
-    tag = "stream" if os.environ.get("ISE_NO_GEMM") == "1" else "gemm div=" + os.environ.get("ISE_GEMM_SAMPLE_DIV", "32")
+    tag = storage + " " + "stream" if os.environ.get("ISE_NO_GEMM") == "1" else "gemm div=" + os.environ.get("ISE_GEMM_SAMPLE_DIV", "32")
     print(tag, "(nq, ms, kQPS, TFLOP/s):", out, index.exact_stats())
 else:
     arms = [{"ISE_NO_GEMM": "1"}, {}, {"ISE_GEMM_SAMPLE_DIV": "64"}, {"ISE_GEMM_SAMPLE_DIV": "16"}]

@@ -412,3 +412,54 @@ def test_large_batch_path_on_concurrent_streams_and_threads(faiss):
     [t.join() for t in th]
     assert not errors, errors
     assert index.exact_stats()["gemm_chunks"] >= 6 * 5  # 256, 700, 1100 (two chunks) and 300 queries, six times each
+
+
+@pytest.mark.parametrize("metric", [ko.METRIC_INNER_PRODUCT, L2])
+@pytest.mark.parametrize("d,nq,k", [(512, 256, 10), (512, 1024, 10), (128, 300, 32), (384, 257, 1)])
+def test_bf16_large_batch_gemm_path(faiss, metric, d, nq, k):
+    """BASELINE config 5's shape: bf16 rows, batches of >= 256 queries -> the bf16 GEMM-shaped pass
+    (csrc/ise_gemm_bf16.hpp).  Against the exact oracle on the rounded values, and bit for bit against the
+    streaming passes for the inner product (the same two accumulator chains)."""
+    import torch
+
+    rng = np.random.default_rng(d + nq + k + metric)
+    n = 150_000
+    xb = rng.standard_normal((n, d)).astype(np.float32)
+    xq = rng.standard_normal((nq, d)).astype(np.float32)
+    if metric == ko.METRIC_INNER_PRODUCT:  # cosine: normalised rows, as create_search_index("cosine") builds them
+        xb, xq = ko.normalize_rows(xb), ko.normalize_rows(xq)
+    rb = torch.from_numpy(xb).to(torch.bfloat16).to(torch.float32).numpy()
+    rq = torch.from_numpy(xq).to(torch.bfloat16).to(torch.float32).numpy()
+    index = faiss.IndexFlat(d, metric, storage="bf16")
+    index.add(xb)
+    D, I = index.search(xq, k)
+    assert index.exact_stats()["gemm_chunks"] == 1
+    D_ref, I_ref = ko.knn_exact(rb, rq, k, metric)
+    assert_knn_matches(D, I, D_ref, I_ref, rb, rq, metric, gap=ko.kth_gap(rb, rq, k, metric))
+    if metric == ko.METRIC_INNER_PRODUCT:
+        Ds = np.concatenate([index.search(xq[i:i + 64], k)[0] for i in range(0, nq, 64)])
+        Is = np.concatenate([index.search(xq[i:i + 64], k)[1] for i in range(0, nq, 64)])
+        assert np.array_equal(Is, I) and np.array_equal(Ds, D)
+
+
+def test_bf16_large_batch_overflow_reruns_through_the_streaming_passes(faiss):
+    """5000 copies of one row: every copy passes any query's admit threshold, the candidate buffers
+    overflow, and the streaming passes queued behind the GEMM path (gated on the overflow) answer
+    instead -- lowest ids first."""
+    import torch
+
+    rng = np.random.default_rng(17)
+    n, d, nq, k = 140_000, 128, 256, 10
+    xb = ko.normalize_rows(rng.standard_normal((n, d)).astype(np.float32))
+    dup = np.sort(rng.choice(n, 5000, replace=False))
+    xb[dup] = xb[dup[0]]
+    xq = np.ascontiguousarray(np.repeat(xb[dup[0]][None, :], nq, axis=0) + 0.001 * rng.standard_normal((nq, d)).astype(np.float32))
+    rb = torch.from_numpy(xb).to(torch.bfloat16).to(torch.float32).numpy()
+    rq = torch.from_numpy(xq).to(torch.bfloat16).to(torch.float32).numpy()
+    index = faiss.IndexFlatIP(d, storage="bf16")
+    index.add(xb)
+    D, I = index.search(xq, k)
+    assert index.exact_stats()["gemm_chunks"] == 1
+    assert (I == dup[:k][None, :]).all(), "ties must resolve to the lowest ids"
+    D_ref, I_ref = ko.knn_exact(rb, rq, k, ko.METRIC_INNER_PRODUCT)
+    assert_knn_matches(D, I, D_ref, I_ref, rb, rq, ko.METRIC_INNER_PRODUCT)
