@@ -7,7 +7,7 @@ Differences, all deliberate:
     (defaults ``data`` / ``models``);
   * ``METHOD`` defaults to DNN, the scoped hot path (the reference defaults to BOVW,
     backend/config.py:61);
-  * ``DNN_BATCH_SIZE`` and ``DECODE_WORKERS`` are new knobs of the batched extractor;
+  * ``DNN_BATCH_SIZE``, ``DECODE_WORKERS`` and ``DECODE_PROCESSES`` are new knobs of the batched extractor;
   * knobs of out-of-scope subsystems (BoVW grid search, cluster scoring) are not carried over.
 """
 import logging
@@ -57,6 +57,7 @@ class Config:
     DNN_INDEX_PATH = _model_file("resnet50_dnn_index.faiss")
     DNN_BATCH_SIZE = 64                     # images per forward pass (the reference runs batch 1)
     DECODE_WORKERS = 8                      # threads decoding images ahead of the GPU batches
+    DECODE_PROCESSES = 0                    # > 0: decode in that many spawned processes instead (past ~2 k images/s)
 
     # ---- BoVW artefacts the hot path still consults
     BOVW_CORNER_DESCRIPTIONS_PATH = _model_file("bovw_corner_descriptions.joblib")  # quirk 5.9-5

@@ -814,7 +814,10 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
 #define GEMM_SAMPLE_SLABS 128 /* 128-row slabs in the threshold sample (16384 rows), spread over the index */
 static bool gemm_applies(const ise_index* h, long long nq, int k) {
     static const bool off = [] { const char* e = getenv("ISE_NO_GEMM"); return e && e[0] == '1'; }();
-    if (off || nq < GEMM_MIN_NQ || h->n < 128ll * 1024) return false;  // shorter indexes: the streaming passes are as fast
+    static const long long min_nq = [] { const char* e = getenv("ISE_GEMM_MIN_NQ"); const int v = e ? atoi(e) : 0; return (long long)(v >= 17 ? v : GEMM_MIN_NQ); }();
+    // measured crossover at 1M x 512: float32 L2 between 192 and 256 queries, bf16 rows (16x the MFMA rate) at 128
+    const long long need = h->storage == ISE_STORE_BF16 ? std::min<long long>(min_nq, 128) : min_nq;
+    if (off || nq < need || h->n < 128ll * 1024) return false;  // shorter indexes: the streaming passes are as fast
     if (h->dp > 512 || h->dp % 128 != 0) return false;            // the row tiles live in <= 128 VGPRs
     if (h->storage == ISE_STORE_BF16) return k <= KPASS_MAX;      // either metric (ise_gemm_bf16.hpp)
     if (!uses_shift(h)) return false;                             // float32 inner product: the streaming passes

@@ -148,6 +148,19 @@ class CNNDescriptor:
     extract = describe  # name used by BASELINE.json's north_star
 
 
+class _NullContext:
+    """``with`` wrapper for an executor that outlives the block."""
+
+    def __init__(self, obj):
+        self.obj = obj
+
+    def __enter__(self):
+        return self.obj
+
+    def __exit__(self, *a):
+        return False
+
+
 class Descriptions(defaultdict):
     """What ``Describer.describe`` returns: the reference's ``{name: [per-image arrays]}`` dict
     (backend/descriptors.py:77,99-101) plus, beside it, the path each array came from."""
@@ -212,6 +225,31 @@ class Describer:
                     print(f"ERROR: Problem describing image '{img_path}'\n '{e}'")
         pending.clear()
 
+    def _process_pool(self, procs: int):
+        from concurrent.futures import ProcessPoolExecutor
+        import multiprocessing as mp
+
+        pool = getattr(self, "_pool", None)
+        if pool is None or getattr(self, "_pool_size", 0) != procs:
+            if pool is not None:
+                pool.shutdown(wait=False, cancel_futures=True)
+            # spawn, not fork: the parent has the GPU open
+            self._pool = ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn"))
+            self._pool_size = procs
+        return self._pool
+
+    def close(self):
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=False, cancel_futures=True)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _safe_read(self, img_path):
         try:
             return img_path, self.read_image(img_path), None
@@ -227,9 +265,15 @@ class Describer:
         descriptions = Descriptions()
         pending = []
         paths = np.asarray(images_paths).ravel().tolist()
-        workers = max(1, int(getattr(config, "DECODE_WORKERS", 8)))
+        procs = max(0, int(getattr(config, "DECODE_PROCESSES", 0)))
+        workers = procs or max(1, int(getattr(config, "DECODE_WORKERS", 8)))
         window = max(workers * 4, self.batch_size)  # decoded images held ahead of the GPU: bounded
-        with ThreadPoolExecutor(max_workers=workers) as pool:
+        # DECODE_PROCESSES > 0: a pool of spawned processes (the PIL thread pool tops out near 2 k images/s on
+        # the GIL-bound array conversion, scripts/feed_rate.py); the pool lives as long as the Describer
+        read = self._safe_read
+        if procs:
+            from ._decode import read_image_bgr as read
+        with (_NullContext(self._process_pool(procs)) if procs else ThreadPoolExecutor(max_workers=workers)) as pool:
             inflight = collections.deque()
             it = iter(paths)
             while True:
@@ -237,7 +281,7 @@ class Describer:
                     nxt = next(it, None)
                     if nxt is None:
                         break
-                    inflight.append(pool.submit(self._safe_read, nxt))
+                    inflight.append(pool.submit(read, nxt))
                 if not inflight:
                     break
                 img_path, image, err = inflight.popleft().result()  # input order is kept

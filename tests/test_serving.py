@@ -215,3 +215,24 @@ def test_indexer_engine_route_end_to_end_on_gpu(tmp_path, monkeypatch):
             assert [p[0] for p in pred] == sorted(p[0] for p in pred)
     finally:
         engine.index, engine.images_paths, engine.descriptor = saved
+
+
+def test_process_pool_decoder_gives_the_same_descriptions(tmp_path, monkeypatch):
+    """DECODE_PROCESSES > 0: spawned decode workers (no torch, no HIP in them) feed the same batches in the
+    same order, skip the same broken files and leave the same described_paths as the thread pool."""
+    from image_search_engine_amd import descriptors as ds
+
+    monkeypatch.setattr(ds.config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib", raising=False)
+    rng = np.random.default_rng(3)
+    paths = _write_images(tmp_path / "data", 23, rng, size=24)
+    paths[7].write_bytes(b"broken")
+    arr = np.array(paths).reshape(-1, 1)
+    outs = {}
+    for procs in (0, 3):
+        monkeypatch.setattr(ds.config, "DECODE_PROCESSES", procs, raising=False)
+        describer = ds.Describer({"conv_features": _MeanColourDescriptor()}, batch_size=5)
+        out = ds.describe_dataset(describer, arr)
+        outs[procs] = (np.concatenate([np.asarray(o) for o in out]), list(describer.described_paths))
+        describer.close()
+    assert len(outs[0][1]) == 22 and outs[0][1] == outs[3][1]
+    assert np.array_equal(outs[0][0], outs[3][0])
