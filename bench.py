@@ -193,7 +193,8 @@ def main():
         # (bucketed collective), a bucket per stream, four buckets in flight; results come back one
         # bucket late, everything is drained inside the timed region
         depth = max(1, int(os.environ.get("ISE_BENCH_BUCKET", "4")))
-        pipe = SearchPipeline(index, nq, k, depth=depth, buckets=4)
+        n_buckets = max(2, int(os.environ.get("ISE_BENCH_BUCKETS", "4")))
+        pipe = SearchPipeline(index, nq, k, depth=depth, buckets=n_buckets)
 
         def run(steps):
             out = None
@@ -298,7 +299,7 @@ def main():
             "config": {"workload": f"{n}x{d} fp32 uniform[0,1) index (default_rng 1234), L2, k={k}, "
                                    f"nq={nq} queries per step, index resident in HBM, "
                                    + (f"row-sharded over {world} GPUs, one all-gather ({index.collective}) + merge per {depth} "
-                                      f"steps, 4 buckets (streams) in flight" if sharded else
+                                      f"steps, {n_buckets} buckets (streams) in flight" if sharded else
                                       f"steps issued round-robin on {n_streams} HIP streams")
                                    + f"; {CLOCK_WARMUP_STEPS} untimed steps ahead of the warm-up bring the GPU out of "
                                      f"its idle power state",

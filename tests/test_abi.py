@@ -67,3 +67,24 @@ def test_product_package_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "flat_oracle" not in src and "knn_oracle" not in src, f
+
+
+def test_comm_entry_points_without_a_gpu():
+    """ise_comm_*: the id can be drawn anywhere librccl loads; joining needs a GPU and says so."""
+    import torch
+
+    from image_search_engine_amd import _native as n
+
+    buf = ctypes.create_string_buffer(128)
+    rc = n.lib.ise_comm_unique_id(buf)
+    assert rc in (0, n.E_NODEVICE)          # E_NODEVICE: no librccl on this machine
+    assert n.lib.ise_comm_unique_id(None) == n.E_INVALID
+    h = ctypes.c_void_p()
+    assert n.lib.ise_comm_create(ctypes.byref(h), buf.raw, 0, 0, 0) == n.E_INVALID      # world < 1
+    assert n.lib.ise_comm_create(ctypes.byref(h), buf.raw, 2, 2, 0) == n.E_INVALID      # rank out of range
+    assert n.lib.ise_comm_create(None, buf.raw, 1, 0, 0) == n.E_INVALID
+    assert n.lib.ise_comm_allgather_keys(None, None, None, 4, None) == n.E_INVALID
+    assert n.lib.ise_comm_destroy(None) == 0
+    if not torch.cuda.is_available() and rc == 0:
+        assert n.lib.ise_comm_create(ctypes.byref(h), buf.raw, 1, 0, 0) == n.E_NODEVICE
+        assert b"GPU" in n.lib.ise_last_error()

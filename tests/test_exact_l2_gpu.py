@@ -415,7 +415,7 @@ def test_large_batch_path_on_concurrent_streams_and_threads(faiss):
 
 
 @pytest.mark.parametrize("metric", [ko.METRIC_INNER_PRODUCT, L2])
-@pytest.mark.parametrize("d,nq,k", [(512, 256, 10), (512, 1024, 10), (128, 300, 32), (384, 257, 1)])
+@pytest.mark.parametrize("d,nq,k", [(512, 256, 10), (512, 1024, 10), (128, 300, 32), (384, 257, 1), (256, 128, 5)])
 def test_bf16_large_batch_gemm_path(faiss, metric, d, nq, k):
     """BASELINE config 5's shape: bf16 rows, batches of >= 256 queries -> the bf16 GEMM-shaped pass
     (csrc/ise_gemm_bf16.hpp).  Against the exact oracle on the rounded values, and bit for bit against the
