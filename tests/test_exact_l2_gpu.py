@@ -318,7 +318,8 @@ def test_concurrent_host_searches_overlap_and_agree(faiss):
 
 
 # ---------------------------------------------------------------- large batches: the GEMM-shaped path
-@pytest.mark.parametrize("d,nq,k", [(512, 256, 10), (512, 300, 20), (128, 1024, 10), (256, 333, 1), (384, 260, 28)])
+@pytest.mark.parametrize("d,nq,k", [(512, 256, 10), (512, 300, 20), (128, 1024, 10), (256, 333, 1), (384, 260, 28),
+                                    (512, 64, 10), (512, 100, 10)])
 def test_large_batch_gemm_path_matches_oracle(faiss, d, nq, k):
     """nq >= 256 against a float32 L2 index of >= 128k rows: strided-sample thresholds, one GEMM-shaped
     pass, candidate select, exact re-rank (csrc/ise_gemm_scan.hpp).  Same answers as the oracle and as
@@ -335,7 +336,8 @@ def test_large_batch_gemm_path_matches_oracle(faiss, d, nq, k):
     before = index.exact_stats()
     D, I = index.search(xq, k)
     after = index.exact_stats()
-    assert after["gemm_chunks"] == before["gemm_chunks"] + 1, "the batch did not take the large-batch path"
+    # from 256 queries on: the GEMM-shaped pass; below: two- and three-tile streaming passes
+    assert after["gemm_chunks"] == before["gemm_chunks"] + (1 if nq >= 256 else 0), "unexpected path"
     assert after["exact_scan"] == before["exact_scan"], "certificate failed on uniform data"
     Dr, Ir, _ = fo.knn_flat(xb, xq, k, 1, 16)
     assert_knn_matches(D, I, Dr, Ir, xb, xq, L2, atol=ATOL_UNIFORM)
