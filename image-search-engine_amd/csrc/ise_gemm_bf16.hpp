@@ -16,6 +16,7 @@
 #include "ise_gemm_scan.hpp"
 
 #define GB_XT 2 /* row tiles per wave */
+#define GB_GQ 64 /* queries per LDS stage: two sweeps of 32 per barrier, so that a stage's compute covers the next stage's LDS-DMA */
 
 // queries -> bf16 pairs, padded rows + |x|^2 of the rounded values (wave per query)
 __global__ __launch_bounds__(256) void qprep_bf16_kernel(const float* __restrict__ q, int nq, int nq_pad, int d, int S,
@@ -42,23 +43,23 @@ __global__ __launch_bounds__(256) void qprep_bf16_kernel(const float* __restrict
 }
 
 // NS: k-steps of 32 bf16 (64 bytes) per row
-template <int NS, bool DUMP>
+template <int NS, bool DUMP, bool L2>
 __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanParams p) {
     extern __shared__ __align__(16) unsigned char smem_gb[];
     const int S = p.S;  // 4-byte units per LDS / qprep row
-    float* qbuf0 = reinterpret_cast<float*>(smem_gb);  // [GQ][S] (bf16 pairs)
-    float* qbuf1 = qbuf0 + (size_t)GQ * S;
-    float* tauL = qbuf1 + (size_t)GQ * S;              // [GEMM_NQ_MAX]
+    float* qbuf0 = reinterpret_cast<float*>(smem_gb);  // [GB_GQ][S] (bf16 pairs)
+    float* qbuf1 = qbuf0 + (size_t)GB_GQ * S;
+    float* tauL = qbuf1 + (size_t)GB_GQ * S;           // [GEMM_NQ_MAX]
     float* xnL = tauL + GEMM_NQ_MAX;                   // [GEMM_NQ_MAX]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int nstages = p.nq_pad / GQ;
-    const bool l2 = p.metric == ISE_METRIC_L2;
+    const int nstages = p.nq_pad / GB_GQ;
+    constexpr bool l2 = L2;
     constexpr int ROWS = 8 * GB_XT * 16;  // rows per slab
 
     auto stage_load = [&](int st, float* dst) {
-        const char* src = reinterpret_cast<const char*>(p.qprep) + (size_t)st * GQ * S * 4;
-        const int bytes = GQ * S * 4;
+        const char* src = reinterpret_cast<const char*>(p.qprep) + (size_t)st * GB_GQ * S * 4;
+        const int bytes = GB_GQ * S * 4;
         for (int off = w * 1024; off < bytes; off += 8 * 1024)
             if (off + lane * 16 < bytes)
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + off + lane * 16),
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
     const int first = blockIdx.x / p.qparts, step = gridDim.x / p.qparts;
     const int st0 = part * nstages / p.qparts, st1 = (part + 1) * nstages / p.qparts;
     for (int i = tid; i < p.nq_pad; i += 512) {
-        tauL[i] = DUMP ? 0.f : p.tau[i];
+        // thresholds strictly below FLT_MAX: "score <= tau" then also says "score < FLT_MAX" (and NaN fails it)
+        tauL[i] = DUMP ? 0.f : fminf(p.tau[i], 3.4028233e38f);
         xnL[i] = p.xn[i];
     }
     stage_load(st0, qbuf0);
@@ -86,46 +88,69 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
         const long long row_base = (long long)slab * p.slab_stride * ROWS + w * (GB_XT * 16);
         u32x4 a[GB_XT][NS];
         f32x4 yn[GB_XT];
+        int nv[GB_XT];  // valid rows among this lane's four of each tile: the per-element bound check, once per slab
 #pragma unroll
         for (int xt = 0; xt < GB_XT; xt++) {
+            const long long left = p.n - (row_base + xt * 16 + 4 * g);
+            nv[xt] = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
             const long long rr = min(row_base + xt * 16 + c, p.rows16 - 1);
             const char* rp = xbytes + (size_t)rr * row_b + 16 * g;
 #pragma unroll
             for (int s = 0; s < NS; s++) a[xt][s] = *reinterpret_cast<const u32x4*>(rp + 64 * s);
             yn[xt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (row_base + xt * 16 + 4 * g + 3 < p.rows16)
+            if (l2 && row_base + xt * 16 + 4 * g + 3 < p.rows16)
                 yn[xt] = *reinterpret_cast<const f32x4*>(p.norms + row_base + xt * 16 + 4 * g);
         }
 
         for (int sq = st0; sq < st1; sq++) {
             float* cur = buf ? qbuf1 : qbuf0;
             float* nxt = buf ? qbuf0 : qbuf1;
+#ifdef ISE_ABLATE
+            if (!(p.ablate & 2))
+#endif
             stage_load(sq + 1 == st1 ? st0 : sq + 1, nxt);
 
-            const float* q0 = cur + (size_t)c * S + 4 * g;
+          for (int half = 0; half < GB_GQ / 32; half++) {  // 32 queries at a time: two query tiles
+            const float* q0 = cur + (size_t)(half * 32 + c) * S + 4 * g;
             const float* q1 = q0 + (size_t)16 * S;
             f32x4 acc[GB_XT][2][2];  // [row tile][query tile][k-step parity]: the streaming kernel's two chains
 #pragma unroll
             for (int xt = 0; xt < GB_XT; xt++)
 #pragma unroll
                 for (int t = 0; t < 2; t++) acc[xt][t][0] = acc[xt][t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // B fragments are requested TWO k-steps ahead: a k-step is only 4 MFMAs x 16 cycles, less than an
+            // LDS round trip (the float32 kernel's 8 x 32 cycles cover it with one step of lookahead)
             f32x4 b0 = *reinterpret_cast<const f32x4*>(q0), b1 = *reinterpret_cast<const f32x4*>(q1);
+            f32x4 c0 = b0, c1 = b1;
+            if (NS > 1) {
+                c0 = *reinterpret_cast<const f32x4*>(q0 + 16);
+                c1 = *reinterpret_cast<const f32x4*>(q1 + 16);
+            }
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                f32x4 nb0 = b0, nb1 = b1;
-                if (s + 1 < NS) {
-                    nb0 = *reinterpret_cast<const f32x4*>(q0 + 16 * (s + 1));
-                    nb1 = *reinterpret_cast<const f32x4*>(q1 + 16 * (s + 1));
+                f32x4 n0 = c0, n1 = c1;
+                if (s + 2 < NS) {
+                    n0 = *reinterpret_cast<const f32x4*>(q0 + 16 * (s + 2));
+                    n1 = *reinterpret_cast<const f32x4*>(q1 + 16 * (s + 2));
                 }
                 const bf16x8 bv0 = __builtin_bit_cast(bf16x8, b0), bv1 = __builtin_bit_cast(bf16x8, b1);
 #pragma unroll
                 for (int xt = 0; xt < GB_XT; xt++) {
                     const bf16x8 av = __builtin_bit_cast(bf16x8, a[xt][s]);
+#ifdef ISE_ABLATE
+                    if (p.ablate & 4) {  // operands stay live, no matrix work
+                        acc[xt][0][s & 1] += __builtin_bit_cast(f32x4, a[xt][s]) + b0;
+                        acc[xt][1][s & 1] += b1;
+                        continue;
+                    }
+#endif
                     acc[xt][0][s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv0, acc[xt][0][s & 1], 0, 0, 0);
                     acc[xt][1][s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv1, acc[xt][1][s & 1], 0, 0, 0);
                 }
-                b0 = nb0;
-                b1 = nb1;
+                b0 = c0;
+                b1 = c1;
+                c0 = n0;
+                c1 = n1;
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -133,8 +158,14 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const f32x4 dot = acc[xt][t][0] + acc[xt][t][1];
-                    const int q = sq * GQ + t * 16 + c;
-                    const float xq_n = xnL[q], tq = tauL[q];
+#ifdef ISE_ABLATE
+                    if (p.ablate & 1) {  // keep the accumulators live, skip the bookkeeping
+                        asm volatile("" ::"v"(dot[0]), "v"(dot[1]), "v"(dot[2]), "v"(dot[3]));
+                        continue;
+                    }
+#endif
+                    const int q = sq * GB_GQ + half * 32 + t * 16 + c;
+                    const float xq_n = l2 ? xnL[q] : 0.f, tq = tauL[q];
                     const long long r0 = row_base + xt * 16 + 4 * g;
                     float sc[4];
                     bool pass[4];
@@ -147,13 +178,13 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
                         } else {
                             sc[j] = -dot[j];
                         }
-                        pass[j] = sc[j] <= tq && (r0 + j < p.n) && sc[j] < FLT_MAX;
+                        pass[j] = sc[j] <= tq && j < nv[xt];
                         any |= pass[j];
                     }
                     if constexpr (DUMP) {
                         f32x4 o;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) o[j] = (r0 + j < p.n && sc[j] < FLT_MAX) ? sc[j] : FLT_MAX;
+                        for (int j = 0; j < 4; j++) o[j] = (j < nv[xt] && sc[j] < FLT_MAX) ? sc[j] : FLT_MAX;
                         *reinterpret_cast<f32x4*>(p.dump + (size_t)q * ((size_t)p.slabs * ROWS) + (size_t)slab * ROWS +
                                                   w * (GB_XT * 16) + xt * 16 + 4 * g) = o;
                     } else if (__ballot(any)) {
@@ -175,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
                         }
                     }
                 }
+          }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             buf ^= 1;

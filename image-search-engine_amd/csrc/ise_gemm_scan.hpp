@@ -61,6 +61,7 @@ struct GemmScanParams {
     int slab_stride;
     int qparts;           // the query stages are split over this many blocks per slab (DUMP launches: 1 slab per block)
     float* dump;          // DUMP: [nq_pad][slabs * 128] lower-bound scores (FLT_MAX for rows past the end)
+    int ablate;           // dev builds: 1 = no epilogue, 2 = no query staging, 4 = no MFMA ($ISE_GEMM_ABLATE)
 };
 
 __host__ __device__ constexpr size_t gemm_lds_bytes(int S) {

@@ -904,6 +904,7 @@ static int search_large_chunk(ise_index* h, ise_index::WorkSlot* w, const float*
     gp.beta = exact_beta(h); gp.id_base = id_base;
     gp.wbuf = reinterpret_cast<u32x4*>(w->gemm + gl.wbuf); gp.wcnt = reinterpret_cast<unsigned int*>(w->gemm + gl.wcnt);
     gp.capw = GEMM_CAPW;
+    gp.ablate = 0;
     const int slabs_all = (int)((h->n + 127) / 128);
     const size_t lds = gemm_lds_bytes(S);
     const int ns = h->dp / 16;
@@ -1054,15 +1055,20 @@ static int scan_path_enqueue(ise_index* h, ise_index::WorkSlot* w, const ScanPla
 }
 
 
-template <int NS, bool DUMP>
-static void launch_gemm_bf16_one(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
+template <int NS, bool DUMP, bool L2>
+static void launch_gemm_bf16_metric(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_scan_bf16_kernel<NS, DUMP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_scan_bf16_kernel<NS, DUMP, L2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_scan_bf16_kernel<NS, DUMP>), dim3(grid), dim3(512), lds, st, gp);
+    hipLaunchKernelGGL((gemm_scan_bf16_kernel<NS, DUMP, L2>), dim3(grid), dim3(512), lds, st, gp);
+}
+template <int NS, bool DUMP>
+static void launch_gemm_bf16_one(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
+    if (gp.metric == ISE_METRIC_L2) launch_gemm_bf16_metric<NS, DUMP, true>(grid, lds, st, gp);
+    else launch_gemm_bf16_metric<NS, DUMP, false>(grid, lds, st, gp);
 }
 template <bool DUMP>
 static int launch_gemm_bf16(int ns, int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
@@ -1090,7 +1096,7 @@ static int search_large_chunk_bf16(ise_index* h, ise_index::WorkSlot* w, const f
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(w->gemm + gl.ccnt);
     float* dump = reinterpret_cast<float*>(w->gemm + gl.dump);
     u64* cand = reinterpret_cast<u64*>(w->gemm + gl.cand);
-    const int nq_pad = (int)((nq + GQ - 1) / GQ * GQ);
+    const int nq_pad = (int)((nq + GB_GQ - 1) / GB_GQ * GB_GQ);
     int rc;
 
     if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
@@ -1105,13 +1111,17 @@ static int search_large_chunk_bf16(ise_index* h, ise_index::WorkSlot* w, const f
     gp.nq_pad = nq_pad; gp.beta = 0.f; gp.metric = h->metric; gp.id_base = id_base;
     gp.wbuf = reinterpret_cast<u32x4*>(w->gemm + gl.wbuf); gp.wcnt = reinterpret_cast<unsigned int*>(w->gemm + gl.wcnt);
     gp.capw = GEMM_CAPW;
+    gp.ablate = 0;
+#ifdef ISE_ABLATE
+    if (const char* e = getenv("ISE_GEMM_ABLATE")) gp.ablate = atoi(e);
+#endif
     const int slabs_all = (int)((h->n + ROWS - 1) / ROWS);
-    const size_t lds = (size_t)2 * GQ * S * 4 + (size_t)2 * GEMM_NQ_MAX * 4;
+    const size_t lds = (size_t)2 * GB_GQ * S * 4 + (size_t)2 * GEMM_NQ_MAX * 4;
     const int ns = h->dp / 32;
 
     gp.slabs = std::min(slabs_all, GEMM_SAMPLE_SLABS * 128 / ROWS);  // the same 16384 sample rows
     gp.slab_stride = slabs_all / gp.slabs;
-    const int nstages = nq_pad / GQ;
+    const int nstages = nq_pad / GB_GQ;
     gp.qparts = std::max(1, std::min(nstages, (2 * h->num_cu) / gp.slabs));
     gp.dump = dump;
     if ((rc = launch_gemm_bf16<true>(ns, gp.slabs * gp.qparts, lds, st, gp))) return rc;
