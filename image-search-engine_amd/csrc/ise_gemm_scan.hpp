@@ -168,7 +168,8 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
     const int first = blockIdx.x / p.qparts, step = gridDim.x / p.qparts;
     const int st0 = part * nstages / p.qparts, st1 = (part + 1) * nstages / p.qparts;
     for (int i = tid; i < p.nq_pad; i += 512) {
-        tauL[i] = DUMP ? 0.f : p.tau[i];
+        // thresholds strictly below FLT_MAX: "score <= tau" then also says "score < FLT_MAX" (and NaN fails it)
+        tauL[i] = DUMP ? 0.f : fminf(p.tau[i], 3.4028233e38f);
         xnL[i] = p.xn[i];
     }
     for (int i = tid; i < S; i += 512) muL[i] = i < p.dp ? p.mu[i] : 0.f;
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
         }
         f32x4 yn = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (row_base + 4 * g + 3 < p.rows16) yn = *reinterpret_cast<const f32x4*>(p.norms + row_base + 4 * g);
+        const long long left = p.n - (row_base + 4 * g);
+        const int nv = left >= 4 ? 4 : (left > 0 ? (int)left : 0);  // valid rows among this lane's four: checked once per slab
 
         for (int sq = st0; sq < st1; sq++) {
             float* cur = buf ? qbuf1 : qbuf0;
@@ -236,14 +239,14 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
                 for (int j = 0; j < 4; j++) {
                     const float tt = xq_n + yn[j];
                     lo[j] = fmaf(-p.beta, tt, tt - 2.f * dot[j]);
-                    pass[j] = lo[j] <= tq && (row_base + 4 * g + j < p.n) && lo[j] < FLT_MAX;
+                    pass[j] = lo[j] <= tq && j < nv;
                     any |= pass[j];
                 }
                 if constexpr (DUMP) {  // the threshold sample: every score goes out (rows past the end and NaN as FLT_MAX)
                     f32x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        o[j] = (row_base + 4 * g + j < p.n && lo[j] < FLT_MAX) ? lo[j] : FLT_MAX;
+                        o[j] = (j < nv && lo[j] < FLT_MAX) ? lo[j] : FLT_MAX;
                     *reinterpret_cast<f32x4*>(p.dump + (size_t)q * ((size_t)p.slabs * 128) + (size_t)slab * 128 + w * 16 + 4 * g) = o;
                 } else if (__ballot(any)) {  // rare: ~N kc / sample candidates per query over the whole index
 #pragma unroll
