@@ -69,7 +69,7 @@ def test_random_vs_oracle(faiss, metric, n, d, nq, k):
     assert_knn_matches(D, I, D_ref, I_ref, xb, xq, metric, gap=ko.kth_gap(xb, xq, k, metric))
 
 
-@pytest.mark.parametrize("k", [33, 64, 100, 257])
+@pytest.mark.parametrize("k", [29, 33, 64, 100, 257, 2048])
 def test_large_k_multipass(faiss, k):
     rng = np.random.default_rng(k)
     xb = rng.random((3000, 40), dtype=np.float32)
