@@ -5,9 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_search_engine_amd.faiss_compat as faiss
 d, k = 512, 10
 g = torch.Generator(device="cuda").manual_seed(1)
-for n in (1_000_000,):
+for n in (125_000, 1_000_000):
     xb = torch.rand((n, d), generator=g, device="cuda")
-    for storage, metric in (("f32", 1),):
+    for storage, metric in (("f32", 1), ("f32", 0), ("bf16", 0)):
         index = faiss.IndexFlat(d, metric, storage=storage); index.add_torch(xb)
         row = []
         for nq in (1, 16, 32, 48, 64):
