@@ -486,6 +486,7 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     // next step to be computed.
     f32x4 bcur[T];
     auto load_b = [&](f32x4(&b)[T], int step) {
+        if (ABL(512)) return;  // dev: no LDS reads of the query operand (registers keep whatever they hold)
 #pragma unroll
         for (int t = 0; t < T; t++) b[t] = *reinterpret_cast<const f32x4*>(qrow + (size_t)t * 16 * S + 16 * step);
     };

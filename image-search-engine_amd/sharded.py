@@ -78,16 +78,35 @@ class RcclComm:
         self.device = device
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         buf = ctypes.create_string_buffer(128)
+        id_err = None
         if rank == 0:
-            _n.check(_n.lib.ise_comm_unique_id(buf))
+            try:
+                _n.check(_n.lib.ise_comm_unique_id(buf))
+            except Exception as e:  # noqa: BLE001 -- the broadcast below must still happen: the peers wait in it
+                id_err, buf = e, ctypes.create_string_buffer(128)
         t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
         on_gpu = dist.get_backend(group) == "nccl"
         if on_gpu:
             t = t.to(device)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         raw = bytes(t.cpu().numpy().tobytes())
+        if id_err is not None or not any(raw):  # an all-zero id = rank 0 could not draw one
+            raise RuntimeError(f"no RCCL unique id from rank 0 ({id_err!r})")
         self._h = ctypes.c_void_p()
         _n.check(_n.lib.ise_comm_create(ctypes.byref(self._h), raw, world, rank, device.index))
+
+    def self_test(self, group) -> None:
+        """One tiny all-gather checked on the host (every rank sends its own rank): a communicator that
+        cannot reach its peers shows here, at start-up, not as a wrong merge later."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        send = torch.full((4,), rank, dtype=torch.int64, device=self.device)
+        recv = torch.full((4 * world,), -1, dtype=torch.int64, device=self.device)
+        torch.cuda.synchronize(self.device)
+        self.all_gather_into(recv, send, torch.cuda.current_stream(self.device).cuda_stream)
+        torch.cuda.synchronize(self.device)
+        want = torch.arange(world, dtype=torch.int64).repeat_interleave(4)
+        if not torch.equal(recv.cpu(), want):
+            raise RuntimeError(f"RCCL self-test: rank {rank} gathered {recv.cpu().tolist()}")
 
     def all_gather_into(self, gathered: torch.Tensor, keys: torch.Tensor, stream: int) -> None:
         """gathered (world * n int64, contiguous) <- every rank's keys (n int64), on ``stream``."""
@@ -123,12 +142,37 @@ class ShardedIndexFlat:
         self.id_base = 0
         self._counts = [0] * self.world
         dev = getattr(self.backend, "device", torch.device("cpu"))
-        if collective == "auto":
+        auto = collective == "auto"
+        if auto:
             collective = "rccl" if (dev.type == "cuda" and dist.get_backend(group) == "nccl") else "torch"
         if collective not in ("rccl", "torch"):
             raise ValueError("collective must be 'auto', 'rccl' or 'torch'")
+        self.comm = None
+        if collective == "rccl":
+            # every rank reports whether its communicator came up and passed the self-test; "auto"
+            # then moves ALL ranks to the process group's own all-gather (still RCCL, issued by
+            # torch.distributed) if any of them failed; an explicit "rccl" raises instead
+            err = None
+            try:
+                self.comm = RcclComm(group, dev)
+                self.comm.self_test(group)
+            except Exception as e:  # noqa: BLE001 -- reported below, on every rank
+                err = e
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                if self.comm is not None:
+                    self.comm.close()
+                    self.comm = None
+                if not auto:
+                    raise RuntimeError(f"collective='rccl': the library's communicator failed on some rank"
+                                       f" (this rank: {err!r})")
+                import sys
+
+                print(f"[image_search_engine_amd] rank {self.rank}: library RCCL communicator unavailable ({err!r});"
+                      " using torch.distributed's all-gather", file=sys.stderr, flush=True)
+                collective = "torch"
         self.collective = collective
-        self.comm = RcclComm(group, dev) if collective == "rccl" else None
 
     @staticmethod
     def shard_bounds(n: int, world: int, rank: int):

@@ -38,8 +38,20 @@ def _worker(rank, world, port, backend, q, metric=1, storage="f32", collective="
         n, d, nq, k = 30011, 96, 16, 10
         xb = rng.random((n, d), dtype=np.float32) - np.float32(0.5 if metric == 0 else 0.0)
         xb[n - 5] = xb[7]  # duplicate rows in different shards: the lower global id wins
-        idx = ShardedIndexFlat(d, metric, storage=storage, collective=collective)
-        assert idx.collective == ("rccl" if (backend == "nccl" and collective != "torch") else "torch")
+        if collective == "auto-broken":  # the library's communicator fails its self-test on this rank
+            import image_search_engine_amd.sharded as sh
+
+            def _fail(self, group):
+                raise RuntimeError("injected self-test failure")
+
+            sh.RcclComm.self_test = _fail
+            with pytest.raises(RuntimeError, match="communicator failed"):
+                ShardedIndexFlat(d, metric, storage=storage, collective="rccl")
+            idx = ShardedIndexFlat(d, metric, storage=storage, collective="auto")
+            assert idx.collective == "torch" and idx.comm is None  # every rank moved to the process group's all-gather
+        else:
+            idx = ShardedIndexFlat(d, metric, storage=storage, collective=collective)
+            assert idx.collective == ("rccl" if (backend == "nccl" and collective != "torch") else "torch")
         idx.add_global(torch.from_numpy(xb).to(dev))
         lo, hi = ShardedIndexFlat.shard_bounds(n, world, rank)
         assert idx.backend.ntotal == hi - lo and idx.id_base == lo and idx.ntotal == n
@@ -98,6 +110,7 @@ def _free_port():
     ("gloo", 2, 0, "f32", "auto"),     # inner product
     ("gloo", 2, 0, "bf16", "auto"),    # BASELINE config 5: bf16 rows, inner product
     ("nccl", 1, 0, "bf16", "auto"),
+    ("nccl", 1, 1, "f32", "auto-broken"),  # start-up self-test fails: "rccl" raises, "auto" falls back to torch's
 ])
 def test_sharded_hip_backend(backend, world, metric, storage, collective):
     ctx = mp.get_context("spawn")
