@@ -18,6 +18,7 @@ differs from cv2's 11-bit fixed-point uint8 resize by <= 1 LSB before normalisat
 from __future__ import annotations
 
 import collections
+import threading
 from collections import defaultdict
 from typing import Protocol
 
@@ -65,7 +66,22 @@ class CNNDescriptor:
         self.preprocessor = None
         self.feature_extractor = None
         self.projection = None
+        self._stage = {"bufs": [None, None], "events": [None, None], "turn": 0}
+        self._stage_lock = threading.Lock()  # Flask request threads share one descriptor
         self.initialize_model()
+
+    def __getstate__(self):  # copies and pickles leave the staging buffers and their lock behind
+        d = dict(self.__dict__)
+        d.pop("_stage", None)
+        d.pop("_stage_lock", None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._stage = {"bufs": [None, None], "events": [None, None], "turn": 0}
+        self._stage_lock = threading.Lock()
+        if getattr(self.preprocessor, "__self__", None) is not None:
+            self.preprocessor = self._preprocess_batch
 
     def initialize_model(self):
         if self.model == DnnModels.RESNET:
@@ -88,18 +104,73 @@ class CNNDescriptor:
         self._std = torch.tensor(_STD, device=self.device).view(1, 3, 1, 1) * 255.0
 
     # -- preprocessing: A.Resize(224,224, INTER_LINEAR) -> A.Normalize() -> ToTensorV2
+    def _staging(self, nbytes: int):
+        """(buffer, slot): one of two page-locked host buffers used alternately for the batch upload; a
+        buffer is handed out again only after the copy that last read it has completed (its event).
+        Called with ``_stage_lock`` held."""
+        st = self._stage
+        i = st["turn"]
+        st["turn"] = 1 - i
+        if st["events"][i] is not None:
+            st["events"][i].synchronize()
+        buf = st["bufs"][i]
+        if buf is None or buf.numel() < nbytes:
+            cap = max(nbytes, 2 * (buf.numel() if buf is not None else 0), 1 << 20)
+            buf = st["bufs"][i] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        return buf, i
+
     def _preprocess_batch(self, images) -> torch.Tensor:
+        """The whole batch goes up in ONE host-to-device copy (pixels packed back to back in a pinned
+        buffer); images of the same height and width are then resized together.  Per image this is
+        the arithmetic of the one-image path: uint8 -> float, bilinear resize on the float pixels,
+        (v - 255 mean) / (255 std), channel order untouched; rows of the result follow the input order."""
         size = config.RESIZE_SIZE
-        out = []
+        arrs = []
         for im in images:
-            t = torch.from_numpy(np.ascontiguousarray(im)).to(self.device, non_blocking=True)
-            if t.dim() != 3 or t.shape[2] != 3:
+            a = np.ascontiguousarray(im)
+            if a.ndim != 3 or a.shape[2] != 3:
                 raise ValueError("expected an HWC 3-channel uint8 image")
-            t = t.permute(2, 0, 1).unsqueeze(0).float()
-            if t.shape[2] != size or t.shape[3] != size:
-                t = F.interpolate(t, size=(size, size), mode="bilinear", align_corners=False)
-            out.append(t)
-        x = torch.cat(out, 0)
+            if a.dtype != np.uint8:  # what torch.from_numpy(...).float() of the old path accepted
+                a = a.astype(np.float32)
+            arrs.append(a)
+        if not arrs:
+            return torch.empty((0, 3, size, size), device=self.device)
+        if self.device.type != "cuda" or any(a.dtype != np.uint8 for a in arrs):
+            out = []
+            for a in arrs:
+                t = torch.from_numpy(a).to(self.device).permute(2, 0, 1).unsqueeze(0).float()
+                if t.shape[2] != size or t.shape[3] != size:
+                    t = F.interpolate(t, size=(size, size), mode="bilinear", align_corners=False)
+                out.append(t)
+            x = torch.cat(out, 0)
+        else:
+            offs = np.cumsum([0] + [a.size for a in arrs])
+            with self._stage_lock:
+                host, slot = self._staging(int(offs[-1]))
+                hv = host.numpy()
+                for a, o in zip(arrs, offs[:-1]):
+                    hv[o:o + a.size] = a.reshape(-1)
+                dev = host[: int(offs[-1])].to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._stage["events"][slot] = ev
+            groups: dict[tuple, list] = {}
+            for i, a in enumerate(arrs):
+                groups.setdefault(a.shape[:2], []).append(i)
+            x = torch.empty((len(arrs), 3, size, size), dtype=torch.float32, device=self.device)
+            for (h, w), idx in groups.items():
+                n = h * w * 3
+                if len(idx) > 1 and all(offs[j] - offs[i] == n for i, j in zip(idx, idx[1:])):
+                    t = dev[offs[idx[0]]: offs[idx[0]] + n * len(idx)].view(len(idx), h, w, 3)  # neighbours: a view
+                else:
+                    t = torch.stack([dev[offs[i]: offs[i] + n].view(h, w, 3) for i in idx])
+                t = t.permute(0, 3, 1, 2).float()
+                if h != size or w != size:
+                    t = F.interpolate(t, size=(size, size), mode="bilinear", align_corners=False)
+                if len(groups) == 1:
+                    x = t
+                else:
+                    x[torch.as_tensor(idx, device=self.device)] = t
         x = (x - self._mean) / self._std  # (img - mean*255) / (std*255), channel order untouched
         return x.contiguous(memory_format=torch.channels_last)
 
@@ -238,11 +309,33 @@ class Describer:
             self._pool_size = procs
         return self._pool
 
+    def _slot_ring(self, nslots: int):
+        """The pixel hand-over ring of the decode processes (``_decode.SlotRing``), or None when
+        ``config.DECODE_SLOT_BYTES`` is 0 or /dev/shm cannot hold it (results are then pickled)."""
+        slot_bytes = int(getattr(config, "DECODE_SLOT_BYTES", 3 << 20))
+        ring = getattr(self, "_ring", None)
+        if ring is not None and (ring.nslots < nslots or ring.slot_bytes != slot_bytes):
+            ring.close()
+            ring = self._ring = None
+        if ring is None and slot_bytes > 0 and not getattr(self, "_ring_failed", False):
+            from ._decode import SlotRing
+
+            try:
+                ring = self._ring = SlotRing(nslots, slot_bytes)
+            except OSError as e:
+                print(f"NOTE: decode processes return pixels through their pipes ({e})")
+                self._ring_failed = True
+        return ring
+
     def close(self):
         pool = getattr(self, "_pool", None)
         if pool is not None:
             pool.shutdown(wait=False, cancel_futures=True)
             self._pool = None
+        ring = getattr(self, "_ring", None)
+        if ring is not None:
+            ring.close()
+            self._ring = None
 
     def __del__(self):
         try:
@@ -271,8 +364,15 @@ class Describer:
         # DECODE_PROCESSES > 0: a pool of spawned processes (the PIL thread pool tops out near 2 k images/s on
         # the GIL-bound array conversion, scripts/feed_rate.py); the pool lives as long as the Describer
         read = self._safe_read
+        ring = None
         if procs:
             from ._decode import read_image_bgr as read
+            from ._decode import read_image_bgr_into
+
+            # a slot is handed out again only after its image has been flushed: images not yet flushed
+            # number at most window (in flight) + batch_size - 1 (pending)
+            ring = self._slot_ring(window + self.batch_size)
+        seq = 0
         with (_NullContext(self._process_pool(procs)) if procs else ThreadPoolExecutor(max_workers=workers)) as pool:
             inflight = collections.deque()
             it = iter(paths)
@@ -281,13 +381,21 @@ class Describer:
                     nxt = next(it, None)
                     if nxt is None:
                         break
-                    inflight.append(pool.submit(read, nxt))
+                    if ring is not None:
+                        slot = seq % ring.nslots
+                        inflight.append((pool.submit(read_image_bgr_into, nxt, ring.path, slot, ring.slot_bytes), slot))
+                    else:
+                        inflight.append((pool.submit(read, nxt), -1))
+                    seq += 1
                 if not inflight:
                     break
-                img_path, image, err = inflight.popleft().result()  # input order is kept
+                fut, slot = inflight.popleft()
+                img_path, image, err = fut.result()  # input order is kept
                 if err is not None:
                     print(f"ERROR: Problem describing image '{img_path}'\n '{err}'")
                     continue
+                if isinstance(image, tuple):  # a shape: the pixels are in the ring (a view, consumed by _flush)
+                    image = ring.view(slot, image)
                 pending.append((img_path, image))
                 if len(pending) >= self.batch_size:
                     self._flush(pending, descriptions)

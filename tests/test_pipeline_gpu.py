@@ -31,6 +31,30 @@ def test_cnn_gpu_matches_cpu_fp32_reference():
     assert dev.is_cuda and dev.shape == (2, 2048)
 
 
+def test_batched_preprocess_equals_the_one_image_path():
+    """The staged upload (one pinned copy per batch, images of one size resized together) gives, row for
+    row and in input order, exactly what preprocessing each image on its own gives -- mixed sizes,
+    neighbours and non-neighbours of the same size, an image already 224 x 224, several batches in a row
+    (the two staging buffers are reused)."""
+    from image_search_engine_amd.descriptors import CNNDescriptor
+
+    gpu = CNNDescriptor(device="cuda")
+    rng = np.random.default_rng(5)
+    shapes = [(375, 500), (375, 500), (224, 224), (500, 375), (375, 500), (64, 48), (224, 224), (375, 500)]
+    for rnd in range(3):
+        imgs = [rng.integers(0, 256, s + (3,), dtype=np.uint8) for s in shapes[rnd:] + shapes[:rnd]]
+        xb = gpu.preprocessor(imgs)
+        assert xb.shape == (len(imgs), 3, 224, 224) and xb.is_contiguous(memory_format=torch.channels_last)
+        for i, im in enumerate(imgs):
+            assert torch.equal(xb[i], gpu.preprocessor([im])[0]), (rnd, i)
+    cpu = CNNDescriptor(device="cpu")
+    xc = cpu.preprocessor(imgs)
+    assert torch.allclose(xb.cpu(), xc, atol=2e-5)   # bilinear weights on two devices: float rounding only
+    assert gpu.preprocessor([]).shape == (0, 3, 224, 224)
+    with pytest.raises(ValueError):
+        gpu.preprocessor([np.zeros((8, 8), np.uint8)])
+
+
 def test_indexer_then_engine_roundtrip(tmp_path, monkeypatch):
     from PIL import Image
 

@@ -219,20 +219,35 @@ def test_indexer_engine_route_end_to_end_on_gpu(tmp_path, monkeypatch):
 
 def test_process_pool_decoder_gives_the_same_descriptions(tmp_path, monkeypatch):
     """DECODE_PROCESSES > 0: spawned decode workers (no torch, no HIP in them) feed the same batches in the
-    same order, skip the same broken files and leave the same described_paths as the thread pool."""
+    same order, skip the same broken files and leave the same described_paths as the thread pool -- with
+    the pixels handed over in /dev/shm slots (the default), with slots too small for some of the images
+    (those come back through the pipe) and without the ring; the ring file is gone after close()."""
+    import os
+
     from image_search_engine_amd import descriptors as ds
 
     monkeypatch.setattr(ds.config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib", raising=False)
     rng = np.random.default_rng(3)
     paths = _write_images(tmp_path / "data", 23, rng, size=24)
+    paths += _write_images(tmp_path / "data2", 6, rng, size=40)      # 4800 B each: larger than the small slots below
     paths[7].write_bytes(b"broken")
     arr = np.array(paths).reshape(-1, 1)
     outs = {}
-    for procs in (0, 3):
+    for name, procs, slot_bytes in (("threads", 0, 3 << 20), ("ring", 3, 3 << 20), ("small slots", 3, 2048),
+                                    ("no ring", 3, 0)):
         monkeypatch.setattr(ds.config, "DECODE_PROCESSES", procs, raising=False)
+        monkeypatch.setattr(ds.config, "DECODE_SLOT_BYTES", slot_bytes, raising=False)
         describer = ds.Describer({"conv_features": _MeanColourDescriptor()}, batch_size=5)
         out = ds.describe_dataset(describer, arr)
-        outs[procs] = (np.concatenate([np.asarray(o) for o in out]), list(describer.described_paths))
+        outs[name] = (np.concatenate([np.asarray(o) for o in out]), list(describer.described_paths))
+        ring = getattr(describer, "_ring", None)
+        assert (ring is not None) == (procs > 0 and slot_bytes > 0)
+        ring_path = ring.path if ring is not None else None
+        if ring is not None:
+            assert os.path.exists(ring_path) and ring.slot_bytes == slot_bytes and ring.nslots >= 5 + 12
         describer.close()
-    assert len(outs[0][1]) == 22 and outs[0][1] == outs[3][1]
-    assert np.array_equal(outs[0][0], outs[3][0])
+        assert ring_path is None or not os.path.exists(ring_path)
+    assert len(outs["threads"][1]) == 28
+    for name in ("ring", "small slots", "no ring"):
+        assert outs[name][1] == outs["threads"][1], name
+        assert np.array_equal(outs[name][0], outs["threads"][0]), name
