@@ -40,6 +40,20 @@ class SupportsDescribe(Protocol):
     def describe(self, image: np.ndarray) -> np.ndarray: ...
 
 
+class _PendingFeatures:
+    """Features of a batch whose device work may still be running."""
+
+    def __init__(self, host: torch.Tensor, event):
+        self._host, self._event = host, event
+
+    def result(self) -> torch.Tensor:
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+            self._host = self._host.clone()  # out of page-locked memory: callers keep these for the whole dataset
+        return self._host
+
+
 class CNNDescriptor:
     """backend/descriptors.py:142-204 with a batched device path.
 
@@ -206,6 +220,19 @@ class CNNDescriptor:
         """(B, d) float32 CPU tensor."""
         return self.extract_features_batch(images).cpu()
 
+    def describe_batch_async(self, images) -> "_PendingFeatures":
+        """Launch ``describe_batch`` without waiting for the device: upload, network and the copy back
+        into page-locked memory are enqueued; ``.result()`` waits for them and returns the (B, d) float32
+        CPU tensor.  The images may be reused once this returns (their pixels are in the staging buffer)."""
+        f = self.extract_features_batch(images)
+        if not f.is_cuda:
+            return _PendingFeatures(f, None)
+        host = torch.empty(f.shape, dtype=f.dtype, pin_memory=True)
+        host.copy_(f, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return _PendingFeatures(host, ev)
+
     # -- the reference's entry points
     def extract_features(self, image):
         if self.model != DnnModels.RESNET:
@@ -269,14 +296,38 @@ class Describer:
             raise Exception("Problem opening image")
         return np.ascontiguousarray(rgb[:, :, ::-1]).astype(np.uint8)
 
-    def _flush(self, pending, descriptions):
-        if not pending:
+    def _flush(self, pending, descriptions, final: bool = False):
+        """Describe the pending batch.  A descriptor with ``describe_batch_async`` only has its batch
+        LAUNCHED here; the results are collected when the next batch has been launched (or at the end),
+        so the device works on batch i while the host decodes, packs and uploads batch i + 1.  Lists stay
+        in input order: a batch is always collected before the next one is."""
+        if pending:
+            paths, images = zip(*pending)
+            launched = {}
+            for d_name, descriptor in self.descriptors.items():
+                if hasattr(descriptor, "describe_batch_async"):
+                    try:
+                        launched[d_name] = descriptor.describe_batch_async(list(images))
+                    except Exception as e:  # collected below as a failed batch
+                        launched[d_name] = e
+            self._collect(descriptions)
+            self._uncollected = (paths, images, launched)
+            pending.clear()
+        if final:
+            self._collect(descriptions)
+
+    def _collect(self, descriptions):
+        prev, self._uncollected = getattr(self, "_uncollected", None), None
+        if prev is None:
             return
-        paths, images = zip(*pending)
+        paths, images, launched = prev
         for d_name, descriptor in self.descriptors.items():
-            if hasattr(descriptor, "describe_batch"):
+            if d_name in launched or hasattr(descriptor, "describe_batch"):
                 try:
-                    feats = descriptor.describe_batch(list(images))
+                    h = launched.get(d_name)
+                    if isinstance(h, Exception):
+                        raise h
+                    feats = h.result() if h is not None else descriptor.describe_batch(list(images))
                     for f in feats:
                         descriptions[d_name].append(f.reshape(1, -1))
                     descriptions.paths[d_name].extend(paths)
@@ -294,7 +345,6 @@ class Describer:
                     descriptions.paths[d_name].append(img_path)
                 except Exception as e:
                     print(f"ERROR: Problem describing image '{img_path}'\n '{e}'")
-        pending.clear()
 
     def _process_pool(self, procs: int):
         from concurrent.futures import ProcessPoolExecutor
@@ -369,9 +419,9 @@ class Describer:
             from ._decode import read_image_bgr as read
             from ._decode import read_image_bgr_into
 
-            # a slot is handed out again only after its image has been flushed: images not yet flushed
-            # number at most window (in flight) + batch_size - 1 (pending)
-            ring = self._slot_ring(window + self.batch_size)
+            # a slot is handed out again only after its image's batch has been collected: images not yet
+            # collected number at most window (in flight) + batch_size - 1 (pending) + batch_size (launched)
+            ring = self._slot_ring(window + 2 * self.batch_size)
         seq = 0
         with (_NullContext(self._process_pool(procs)) if procs else ThreadPoolExecutor(max_workers=workers)) as pool:
             inflight = collections.deque()
@@ -399,7 +449,7 @@ class Describer:
                 pending.append((img_path, image))
                 if len(pending) >= self.batch_size:
                     self._flush(pending, descriptions)
-        self._flush(pending, descriptions)
+        self._flush(pending, descriptions, final=True)
         return descriptions
 
 

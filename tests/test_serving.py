@@ -251,3 +251,51 @@ def test_process_pool_decoder_gives_the_same_descriptions(tmp_path, monkeypatch)
     for name in ("ring", "small slots", "no ring"):
         assert outs[name][1] == outs["threads"][1], name
         assert np.array_equal(outs[name][0], outs["threads"][0]), name
+
+
+def test_describer_collects_async_batches_in_order(tmp_path, monkeypatch):
+    """A descriptor with describe_batch_async has batch i + 1 launched before batch i is collected; the
+    lists still come out in input order, a batch whose launch or result fails is redone image by image,
+    and the last batch is collected at the end."""
+    from image_search_engine_amd import descriptors as ds
+
+    monkeypatch.setattr(ds.config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib", raising=False)
+    monkeypatch.setattr(ds.config, "DECODE_PROCESSES", 0, raising=False)
+    rng = np.random.default_rng(4)
+    paths = _write_images(tmp_path / "data", 22, rng, size=16)
+    events = []
+
+    class _Async(_MeanColourDescriptor):
+        def __init__(self):
+            super().__init__()
+            self.batches = 0
+
+        def describe_batch_async(self, images):
+            i = self.batches
+            self.batches += 1
+            events.append(("launch", i))
+            if i == 1:
+                raise RuntimeError("launch of batch 1 fails")
+            feats = np.stack([_MeanColourDescriptor.describe(self, im).numpy() for im in images])
+
+            class _H:
+                def result(_self):
+                    events.append(("result", i))
+                    if i == 2:
+                        raise RuntimeError("result of batch 2 fails")
+                    return feats
+
+            return _H()
+
+    desc = _Async()
+    describer = ds.Describer({"conv_features": desc}, batch_size=5)
+    out = describer.describe(np.array(paths))
+    got = np.concatenate([np.asarray(o) for o in out["conv_features"]])
+    from PIL import Image
+
+    want = np.stack([_MeanColourDescriptor().describe(np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1]).numpy()
+                     for p in paths])
+    assert np.array_equal(got, want) and out.paths["conv_features"] == paths
+    # batch i is collected after batch i + 1 has been launched; the failed launch has no result() call
+    assert events == [("launch", 0), ("launch", 1), ("result", 0), ("launch", 2), ("launch", 3), ("result", 2),
+                      ("launch", 4), ("result", 3), ("result", 4)]
