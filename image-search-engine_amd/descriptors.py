@@ -50,7 +50,9 @@ class _PendingFeatures:
         if self._event is not None:
             self._event.synchronize()
             self._event = None
-            self._host = self._host.clone()  # out of page-locked memory: callers keep these for the whole dataset
+            # out of the page-locked buffer (it is reused two batches on); a plain memcpy: a torch CPU op of
+            # this size would wake the intra-op thread pool, whose workers then spin on the decoders' cores
+            self._host = torch.from_numpy(self._host.numpy().copy())
         return self._host
 
 
@@ -165,7 +167,7 @@ class CNNDescriptor:
                 for a, o in zip(arrs, offs[:-1]):
                     hv[o:o + a.size] = a.reshape(-1)
                 dev = host[: int(offs[-1])].to(self.device, non_blocking=True)
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(blocking=True)
                 ev.record(torch.cuda.current_stream(self.device))
                 self._stage["events"][slot] = ev
             groups: dict[tuple, list] = {}
@@ -227,9 +229,18 @@ class CNNDescriptor:
         f = self.extract_features_batch(images)
         if not f.is_cuda:
             return _PendingFeatures(f, None)
-        host = torch.empty(f.shape, dtype=f.dtype, pin_memory=True)
+        # two page-locked result buffers used alternately (allocated once: pinning memory is slow); a
+        # buffer comes round again after the batch in between has been launched, and the Describer has
+        # collected this one by then.  Events are blocking ones: a waiting host thread sleeps, it does not spin
+        with self._stage_lock:
+            out = self._stage.setdefault("out", {"bufs": [None, None], "turn": 0})
+            i = out["turn"]
+            out["turn"] = 1 - i
+            if out["bufs"][i] is None or out["bufs"][i].numel() < f.numel():
+                out["bufs"][i] = torch.empty(max(f.numel(), 1 << 18), dtype=torch.float32, pin_memory=True)
+            host = out["bufs"][i][: f.numel()].view(f.shape)
         host.copy_(f, non_blocking=True)
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(blocking=True)
         ev.record(torch.cuda.current_stream(self.device))
         return _PendingFeatures(host, ev)
 
@@ -305,7 +316,7 @@ class Describer:
             paths, images = zip(*pending)
             launched = {}
             for d_name, descriptor in self.descriptors.items():
-                if hasattr(descriptor, "describe_batch_async"):
+                if hasattr(descriptor, "describe_batch_async") and getattr(config, "DESCRIBE_ASYNC", True):
                     try:
                         launched[d_name] = descriptor.describe_batch_async(list(images))
                     except Exception as e:  # collected below as a failed batch

@@ -31,7 +31,8 @@ def main():
     arr = np.array(paths).reshape(-1, 1)
     res = {"n_images": N, "image_size": [H, W], "formats": "90% JPEG q90, 10% PNG", "host_cpus": len(os.sched_getaffinity(0)),
            "generate_s": round(gen_s, 1), "runs": []}
-    for dtype in (torch.float32, torch.bfloat16):
+    modes = os.environ.get("MODES", "threads,procs,decode").split(",")
+    for dtype in (torch.float32, torch.bfloat16) if "threads" in modes else ():
         desc = ds.CNNDescriptor(dtype=dtype)
         # device-only rate: resident uint8 batches
         x = torch.randint(0, 256, (256, 224, 224, 3), dtype=torch.uint8, device="cuda")
@@ -51,24 +52,30 @@ def main():
                                 "images_per_s": round(N / dt, 1), "device_only_images_per_s": round(dev_rate, 1)})
             print(res["runs"][-1], flush=True)
     # the same with a pool of spawned decode processes (config.DECODE_PROCESSES)
-    for dtype in (torch.float32, torch.bfloat16):
+    for dtype in (torch.float32, torch.bfloat16) if "procs" in modes else ():
         desc = ds.CNNDescriptor(dtype=dtype)
         for procs in (4, 8, 16):
             ds.config.DECODE_PROCESSES = procs
             describer = ds.Describer({"conv_features": desc}, batch_size=128)
             ds.describe_dataset(describer, arr[:512])            # starts the workers
-            t0 = time.time()
-            out = ds.describe_dataset(describer, arr)
-            dt = time.time() - t0
-            assert len(out) == N and len(describer.described_paths) == N
-            res["runs"].append({"dtype": str(dtype).split(".")[-1], "decode_processes": procs, "images_per_s": round(N / dt, 1)})
-            print(res["runs"][-1], flush=True)
+            for rnd in range(2):                                  # the host CPUs are shared: alternate, twice
+                for asyn, slot in ((True, 3 << 20), (False, 3 << 20), (True, 0)):
+                    ds.config.DESCRIBE_ASYNC, ds.config.DECODE_SLOT_BYTES = asyn, slot
+                    t0 = time.time(); c0 = time.process_time()
+                    out = ds.describe_dataset(describer, arr)
+                    dt = time.time() - t0
+                    assert len(out) == N and len(describer.described_paths) == N
+                    res["runs"].append({"dtype": str(dtype).split(".")[-1], "decode_processes": procs, "async": asyn,
+                                        "slot_bytes": slot, "images_per_s": round(N / dt, 1),
+                                        "parent_cpu_us_per_image": round(1e6 * (time.process_time() - c0) / N)})
+                    print(res["runs"][-1], flush=True)
+            ds.config.DESCRIBE_ASYNC, ds.config.DECODE_SLOT_BYTES = True, 3 << 20
             describer.close()
     ds.config.DECODE_PROCESSES = 0
     # decode alone (no GPU): what the thread pool delivers
     from concurrent.futures import ThreadPoolExecutor
     d = ds.Describer({"x": object()})
-    for workers in (1, 8, 16, 32):
+    for workers in (1, 8, 16, 32) if "decode" in modes else ():
         t0 = time.time()
         with ThreadPoolExecutor(workers) as pool:
             list(pool.map(d.read_image, paths[:1500]))
