@@ -45,6 +45,7 @@ PROTOTYPES = [
     ("ise_index_set_shift", _int, [_vp, _vp]),
     ("ise_index_get_shift", _int, [_vp, _vp]),
     ("ise_index_stats", _int, [_vp, _u64p]),
+    ("ise_index_host_stats", _int, [_vp, _u64p]),
     ("ise_index_reserve_workspaces", _int, [_vp, _i64, _int]),
     ("ise_index_add_host", _int, [_vp, _vp, _i64]),
     ("ise_index_add_device", _int, [_vp, _vp, _i64, _vp]),

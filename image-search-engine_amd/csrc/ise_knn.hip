@@ -118,12 +118,28 @@ struct ise_index {
         hipStream_t stream = nullptr;
         float* q_dev = nullptr;  size_t q_elems = 0;
         float* D_dev = nullptr;  long long* I_dev = nullptr;  size_t out_elems = 0;
+        // page-locked staging of a combined batch (queries in, results out)
+        float* q_pin = nullptr;  size_t q_pin_elems = 0;
+        float* D_pin = nullptr;  long long* I_pin = nullptr;  size_t out_pin_elems = 0;
         bool busy = false;
     };
     static constexpr int NHC = 4;
     HostCtx hc[NHC];
     std::mutex hc_mu;
     std::condition_variable hc_cv;
+    // combining of concurrent host searches (ise_index_search_host): callers queue their request; one
+    // of them -- at most CQ_LEADERS at a time -- takes the requests at the head of the queue that ask
+    // for the same k, runs them as ONE batch and hands the results out
+    struct HostReq {
+        const float* q; long long nq; int k; float* D; long long* I;
+        int rc = 0; std::string err; bool done = false;
+        std::condition_variable cv;
+    };
+    static constexpr int CQ_LEADERS = 2;
+    std::mutex cq_mu;
+    std::deque<HostReq*> cq;
+    int cq_leaders = 0;
+    unsigned long long cq_batches = 0, cq_requests = 0;
     int num_cu = 256;
     std::mutex mu_;
 };
@@ -241,6 +257,9 @@ static void free_all(ise_index* h) {
         if (c.q_dev) (void)hipFree(c.q_dev);
         if (c.D_dev) (void)hipFree(c.D_dev);
         if (c.I_dev) (void)hipFree(c.I_dev);
+        if (c.q_pin) (void)hipHostFree(c.q_pin);
+        if (c.D_pin) (void)hipHostFree(c.D_pin);
+        if (c.I_pin) (void)hipHostFree(c.I_pin);
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c = ise_index::HostCtx();
     }
@@ -1279,11 +1298,8 @@ static void release_ctx(ise_index* h, ise_index::HostCtx* c) {
     h->hc_cv.notify_one();
 }
 
-extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq, int k, float* D, int64_t* I) {
-    int rc = check_search_args(h, q, nq, k);
-    if (rc) return rc;
-    if (nq == 0) return ISE_OK;
-    if (!D || !I) return fail(ISE_E_INVALID, "output pointer is NULL");
+// one caller, one scan: queries straight from the caller's memory, results straight into it
+static int search_host_direct(ise_index* h, const float* q, long long nq, int k, float* D, long long* I) {
     DeviceGuard gd(h->device);
     ise_index::HostCtx* c = acquire_ctx(h);
     struct Rel { ise_index* h; ise_index::HostCtx* c; ~Rel() { release_ctx(h, c); } } rel{h, c};
@@ -1310,6 +1326,7 @@ extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq,
         const long long m = std::min<long long>(batch, nq - i0);
         HIP_TRY(hipMemcpyAsync(c->q_dev, q + (size_t)i0 * h->d, (size_t)m * h->d * sizeof(float), hipMemcpyHostToDevice,
                                c->stream));
+        int rc;
         {
             std::lock_guard<std::mutex> lk(h->mu_);
             rc = search_enqueue(h, c->q_dev, m, k, 0u, c->D_dev, c->I_dev, nullptr, c->stream, nullptr);
@@ -1321,6 +1338,136 @@ extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq,
                                c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return ISE_OK;
+}
+
+// Largest number of queries a combined batch holds (0 = every caller runs its own scan).  A scan
+// costs the same for 1 or 16 queries and little more for 64: concurrent one-query
+// callers -- the reference's serving pattern, one search per HTTP request on a threaded Flask
+// (backend/engine.py:55,137) -- share the pass over the index instead of queueing for one each.
+static long long host_combine_max() {
+    static const long long v = [] {
+        const char* e = getenv("ISE_HOST_COMBINE_MAX");
+        const long long x = e ? atoll(e) : 64;
+        return x < 0 ? 0 : std::min<long long>(x, 1024);
+    }();
+    return v;
+}
+
+// the requests of one combined batch (same k): gather -> one upload -> one search -> one download -> scatter
+static int run_combined(ise_index* h, const std::vector<ise_index::HostReq*>& batch, long long total, int k) {
+    DeviceGuard gd(h->device);
+    ise_index::HostCtx* c = acquire_ctx(h);
+    struct Rel { ise_index* h; ise_index::HostCtx* c; ~Rel() { release_ctx(h, c); } } rel{h, c};
+    if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t qe = (size_t)total * h->d, oe = (size_t)total * k;
+    if (qe > c->q_elems) {
+        if (c->q_dev) (void)hipFree(c->q_dev);
+        c->q_dev = nullptr; c->q_elems = 0;
+        HIP_TRY(hipMalloc(&c->q_dev, qe * sizeof(float)));
+        c->q_elems = qe;
+    }
+    if (oe > c->out_elems) {
+        if (c->D_dev) (void)hipFree(c->D_dev);
+        if (c->I_dev) (void)hipFree(c->I_dev);
+        c->D_dev = nullptr; c->I_dev = nullptr; c->out_elems = 0;
+        HIP_TRY(hipMalloc(&c->D_dev, oe * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->I_dev, oe * sizeof(long long)));
+        c->out_elems = oe;
+    }
+    if (qe > c->q_pin_elems) {
+        if (c->q_pin) (void)hipHostFree(c->q_pin);
+        c->q_pin = nullptr; c->q_pin_elems = 0;
+        const size_t want = std::max<size_t>(qe, (size_t)std::max<long long>(host_combine_max(), 1) * h->d);
+        HIP_TRY(hipHostMalloc(&c->q_pin, want * sizeof(float), hipHostMallocDefault));
+        c->q_pin_elems = want;
+    }
+    if (oe > c->out_pin_elems) {
+        if (c->D_pin) (void)hipHostFree(c->D_pin);
+        if (c->I_pin) (void)hipHostFree(c->I_pin);
+        c->D_pin = nullptr; c->I_pin = nullptr; c->out_pin_elems = 0;
+        const size_t want = std::max<size_t>(oe, (size_t)std::max<long long>(host_combine_max(), 1) * k);
+        HIP_TRY(hipHostMalloc(&c->D_pin, want * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&c->I_pin, want * sizeof(long long), hipHostMallocDefault));
+        c->out_pin_elems = want;
+    }
+    size_t off = 0;
+    for (const auto* r : batch) {
+        memcpy(c->q_pin + off * h->d, r->q, (size_t)r->nq * h->d * sizeof(float));
+        off += (size_t)r->nq;
+    }
+    HIP_TRY(hipMemcpyAsync(c->q_dev, c->q_pin, qe * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(h->mu_);
+        rc = search_enqueue(h, c->q_dev, total, k, 0u, c->D_dev, c->I_dev, nullptr, c->stream, nullptr);
+    }
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->D_pin, c->D_dev, oe * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->I_pin, c->I_dev, oe * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    off = 0;
+    for (auto* r : batch) {
+        memcpy(r->D, c->D_pin + off * k, (size_t)r->nq * k * sizeof(float));
+        memcpy(r->I, c->I_pin + off * k, (size_t)r->nq * k * sizeof(long long));
+        off += (size_t)r->nq;
+    }
+    return ISE_OK;
+}
+
+extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq, int k, float* D, int64_t* I) {
+    int rc = check_search_args(h, q, nq, k);
+    if (rc) return rc;
+    if (nq == 0) return ISE_OK;
+    if (!D || !I) return fail(ISE_E_INVALID, "output pointer is NULL");
+    const long long cmax = host_combine_max();
+    // large calls fill their own passes; a large k costs the others more than the shared pass saves
+    if (nq > 16 || nq > cmax || k > KB_MAX) return search_host_direct(h, q, nq, k, D, (long long*)I);
+
+    ise_index::HostReq r;
+    r.q = q; r.nq = nq; r.k = k; r.D = D; r.I = (long long*)I;
+    std::unique_lock<std::mutex> lk(h->cq_mu);
+    h->cq.push_back(&r);
+    while (!r.done) {
+        if (h->cq_leaders < ise_index::CQ_LEADERS && !h->cq.empty()) {
+            // lead: the head of the queue and whatever behind it asks for the same k, up to cmax queries
+            h->cq_leaders++;
+            std::vector<ise_index::HostReq*> batch;
+            long long total = 0;
+            const int bk = h->cq.front()->k;
+            while (!h->cq.empty() && h->cq.front()->k == bk && total + h->cq.front()->nq <= cmax) {
+                batch.push_back(h->cq.front());
+                total += h->cq.front()->nq;
+                h->cq.pop_front();
+            }
+            h->cq_batches++;
+            h->cq_requests += batch.size();
+            lk.unlock();
+            const int brc = run_combined(h, batch, total, bk);
+            const std::string berr = brc ? g_err : std::string();
+            lk.lock();
+            for (auto* b : batch) {
+                b->rc = brc;
+                if (brc) b->err = berr;
+                b->done = true;
+                if (b != &r) b->cv.notify_one();
+            }
+            h->cq_leaders--;
+            if (!h->cq.empty()) h->cq.front()->cv.notify_one();  // the next head leads its own batch
+        } else {
+            r.cv.wait(lk);
+        }
+    }
+    lk.unlock();
+    if (r.rc) return fail(r.rc, r.err);  // the message travels to the caller's own thread
+    return ISE_OK;
+}
+
+extern "C" int ise_index_host_stats(ise_index_t* h, uint64_t* out2) {
+    if (!h || !out2) return fail(ISE_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->cq_mu);
+    out2[0] = h->cq_batches;
+    out2[1] = h->cq_requests;
     return ISE_OK;
 }
 

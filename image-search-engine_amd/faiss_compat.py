@@ -100,6 +100,13 @@ class IndexFlat:
         return {"reranked": int(out[0]), "exact_scan": int(out[1]), "shift_updates": int(out[2]),
                 "gemm_chunks": int(out[3])}
 
+    def host_stats(self) -> dict:
+        """Combining of concurrent ``search`` calls (include/ise_knn.h, ise_index_host_stats): how many
+        shared batches ran and how many calls they served."""
+        out = (ctypes.c_uint64 * 2)()
+        _n.check(_n.lib.ise_index_host_stats(self._h, out))
+        return {"combined_batches": int(out[0]), "combined_calls": int(out[1])}
+
     def reserve(self, nq: int, k: int) -> None:
         """Size every internal workspace for batches of ``nq`` queries / ``k`` results now, so that the
         first search of that shape allocates nothing (serving loops, bench.py)."""

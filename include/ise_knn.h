@@ -109,6 +109,13 @@ int ise_index_reconstruct_host(ise_index_t* h, int64_t i0, int64_t n, float* out
  * q: nq x d float32; D: nq x k float32; I: nq x k int64. */
 int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq, int k,
                           float* D, int64_t* I);
+/* Thread-safe, and concurrent small calls SHARE a pass over the index: calls with nq <= 16 and
+ * k <= 32 that arrive while others are waiting or running are run together as one batch of up to
+ * $ISE_HOST_COMBINE_MAX (default 64; 0 = never) queries of the same k, each caller getting exactly
+ * the rows it would have got alone.  This is the reference's serving pattern -- one query per HTTP
+ * request on a threaded Flask (backend/engine.py:55,137) -- where a scan costs the same for 1 or 16
+ * queries.  ise_index_host_stats: out2[0] = batches run that way, out2[1] = calls they served. */
+int ise_index_host_stats(ise_index_t* h, uint64_t* out2);
 int ise_index_search_device(ise_index_t* h, const float* q_dev, int64_t nq, int k,
                             float* D_dev, int64_t* I_dev, void* stream);
 

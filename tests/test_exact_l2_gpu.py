@@ -317,6 +317,66 @@ def test_concurrent_host_searches_overlap_and_agree(faiss):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("metric", [L2, 0])
+def test_concurrent_small_searches_share_a_pass(faiss, metric):
+    """Concurrent small host searches are combined into shared batches (include/ise_knn.h,
+    ise_index_search_host): every caller gets, bit for bit, what it gets when it is alone -- one- to
+    three-query calls, two different k in the mix (only equal k share a batch), a call too large to be
+    combined running beside them -- and the counters show that calls did share batches."""
+    import threading
+
+    rng = np.random.default_rng(12 + metric)
+    n, d = 200_000, 64
+    xb = rng.random((n, d), dtype=np.float32) - np.float32(0.5 if metric == 0 else 0.0)
+    index = faiss.IndexFlat(d, metric)
+    index.add(xb)
+    nthreads, per = 24, 12
+    qs = [[rng.random((1 + (i + j) % 3, d), dtype=np.float32) - np.float32(0.5 if metric == 0 else 0.0)
+           for j in range(per)] for i in range(nthreads)]
+    ks = [10 if i % 4 else 20 for i in range(nthreads)]
+    big = rng.random((40, d), dtype=np.float32)
+    solo = [[index.search(q, ks[i]) for q in qs[i]] for i in range(nthreads)]   # one caller at a time
+    solo_big = index.search(big, 10)
+    s0 = index.host_stats()
+    assert s0["combined_calls"] == nthreads * per and s0["combined_batches"] == nthreads * per  # alone: batches of one
+    for i in (0, 5):  # and the solo answers are right
+        Dr, Ir = ko.knn_exact(xb, qs[i][0], ks[i], metric)
+        assert_knn_matches(solo[i][0][0], solo[i][0][1], Dr, Ir, xb, qs[i][0], metric, atol=ATOL_UNIFORM)
+    errors = []
+    start = threading.Barrier(nthreads + 1)
+
+    def work(i):
+        try:
+            start.wait()
+            for j, q in enumerate(qs[i]):
+                D, I = index.search(q, ks[i])
+                assert np.array_equal(I, solo[i][j][1]) and np.array_equal(D, solo[i][j][0]), (i, j)
+        except Exception as e:
+            errors.append((i, repr(e)))
+
+    def work_big():
+        try:
+            start.wait()
+            for _ in range(4):
+                D, I = index.search(big, 10)
+                assert np.array_equal(I, solo_big[1]) and np.array_equal(D, solo_big[0])
+        except Exception as e:
+            errors.append(("big", repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)] + [threading.Thread(target=work_big)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    s1 = index.host_stats()
+    calls, batches = s1["combined_calls"] - s0["combined_calls"], s1["combined_batches"] - s0["combined_batches"]
+    assert calls == nthreads * per            # the 40-query calls went their own way
+    assert batches < calls, (batches, calls)  # 24 threads hammering one index: some calls shared a pass
+    with pytest.raises(AssertionError):       # Faiss's own argument check (k > 0), before the library is entered
+        index.search(qs[0][0], 0)
+    D, I = index.search(qs[0][0], ks[0])
+    assert np.array_equal(I, solo[0][0][1])
+
+
 # ---------------------------------------------------------------- large batches: the GEMM-shaped path
 @pytest.mark.parametrize("d,nq,k", [(512, 256, 10), (512, 300, 20), (128, 1024, 10), (256, 333, 1), (384, 260, 28),
                                     (512, 64, 10), (512, 100, 10)])
