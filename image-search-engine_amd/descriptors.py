@@ -56,6 +56,14 @@ class _PendingFeatures:
         return self._host
 
 
+class _DescribeRequest:
+    __slots__ = ("image", "result", "error", "alone", "done", "event")
+
+    def __init__(self, image):
+        self.image, self.result, self.error, self.alone, self.done = image, None, None, False, False
+        self.event = threading.Event()
+
+
 class CNNDescriptor:
     """backend/descriptors.py:142-204 with a batched device path.
 
@@ -84,18 +92,24 @@ class CNNDescriptor:
         self.projection = None
         self._stage = {"bufs": [None, None], "events": [None, None], "turn": 0}
         self._stage_lock = threading.Lock()  # Flask request threads share one descriptor
+        self._init_combining()
         self.initialize_model()
+
+    def _init_combining(self):
+        self._cq, self._cq_leader, self._cq_lock = collections.deque(), False, threading.Lock()
+        self.combined_batches = self.combined_calls = 0
 
     def __getstate__(self):  # copies and pickles leave the staging buffers and their lock behind
         d = dict(self.__dict__)
-        d.pop("_stage", None)
-        d.pop("_stage_lock", None)
+        for name in ("_stage", "_stage_lock", "_cq", "_cq_leader", "_cq_lock"):
+            d.pop(name, None)
         return d
 
     def __setstate__(self, d):
         self.__dict__.update(d)
         self._stage = {"bufs": [None, None], "events": [None, None], "turn": 0}
         self._stage_lock = threading.Lock()
+        self._init_combining()
         if getattr(self.preprocessor, "__self__", None) is not None:
             self.preprocessor = self._preprocess_batch
 
@@ -251,10 +265,78 @@ class CNNDescriptor:
         return self._forward(self.preprocessor([image])).cpu().flatten()
 
     def describe(self, image: np.ndarray):
-        with torch.no_grad():
-            return self.extract_features(image)
+        """One image -> flat (d,) CPU tensor (backend/descriptors.py:198-204).  Calls that arrive from
+        several threads while the device is busy -- Flask request threads, backend/engine.py:78,137 -- are
+        run together as one batch (``config.DESCRIBE_COMBINE_MAX`` images, 0 = never): a ResNet-50 forward
+        costs about the same for 1 image as for 16.  A lone caller is served at once."""
+        cmax = int(getattr(config, "DESCRIBE_COMBINE_MAX", 32))
+        if cmax <= 1:
+            with torch.no_grad():
+                return self.extract_features(image)
+        # One leader at a time; while the flag is up new calls queue behind it and sleep on their OWN
+        # event (a shared condition variable would wake every waiter at every batch, and in Python each
+        # of them wants the interpreter lock back).  A leader runs one batch -- its own request is at the
+        # head of it -- wakes the callers it served and promotes the next head of the queue.
+        req = _DescribeRequest(image)
+        with self._cq_lock:
+            self._cq.append(req)
+            lead = not self._cq_leader
+            if lead:
+                self._cq_leader = True
+        if not lead:
+            req.event.wait()          # served, or promoted to leader
+        if not req.done:
+            with self._cq_lock:
+                batch = [self._cq.popleft() for _ in range(min(len(self._cq), cmax))]
+            feats, err = None, None
+            try:
+                if len(batch) == 1:
+                    with torch.no_grad():
+                        feats = [self.extract_features(batch[0].image)]
+                else:
+                    # batch sizes are rounded up to a power of two (the last image repeated): MIOpen
+                    # tunes every new shape once, for up to a second -- five shapes instead of thirty-one
+                    images = [b.image for b in batch]
+                    images += [images[-1]] * ((1 << (len(images) - 1).bit_length()) - len(images))
+                    feats = list(self.describe_batch(images))[: len(batch)]
+                    self.combined_batches += 1
+                    self.combined_calls += len(batch)
+            except Exception as e:  # noqa: BLE001 -- handed to the caller(s) below
+                err = e
+            for i, b in enumerate(batch):
+                if err is None:
+                    b.result = feats[i].flatten()
+                elif len(batch) == 1:
+                    b.error = err
+                else:
+                    b.alone = True   # one bad image must not fail its neighbours: everyone retries alone
+                b.done = True
+                if b is not req:
+                    b.event.set()
+            with self._cq_lock:
+                if self._cq:
+                    self._cq[0].event.set()   # the next head leads (the flag stays up for it)
+                else:
+                    self._cq_leader = False
+        if req.alone:
+            with torch.no_grad():
+                return self.extract_features(image)
+        if req.error is not None:
+            raise req.error
+        return req.result
 
     extract = describe  # name used by BASELINE.json's north_star
+
+    def warm_up(self, shape=(375, 500)) -> None:
+        """Run every batch size concurrent ``describe`` calls can produce (1 and the powers of two up to
+        ``config.DESCRIBE_COMBINE_MAX``) once: the convolution library tunes a new shape for up to a second,
+        which a server wants at start-up, not inside a request."""
+        cmax = max(1, int(getattr(config, "DESCRIBE_COMBINE_MAX", 32)))
+        img = np.zeros(tuple(shape) + (3,), np.uint8)
+        b = 1
+        while b <= cmax:
+            self.describe_batch([img] * b)
+            b *= 2
 
 
 class _NullContext:

@@ -54,6 +54,8 @@ def load(index_path=None, paths=None, desc=None):
     print(f"There are {index.ntotal} images in the index.")
     if desc is not None:
         descriptor = desc
+        if hasattr(desc, "warm_up") and getattr(desc, "device", None) is not None and desc.device.type == "cuda":
+            desc.warm_up()   # the batch shapes combined request threads will produce (descriptors.CNNDescriptor.describe)
     return index
 
 

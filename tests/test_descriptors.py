@@ -127,3 +127,38 @@ def test_batchnorm_folding_keeps_the_function(cnn):
     a, b = plain.describe(img).numpy(), folded.describe(img).numpy()
     assert np.abs(a - b).max() <= 1e-3 * max(1.0, np.abs(a).max())
     assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.feature_extractor.modules())
+
+
+def test_concurrent_describe_calls_share_a_forward_pass(cnn):
+    """Flask request threads (backend/engine.py:78,137) calling describe() at once are served by shared
+    batches: same features as alone (to float rounding: the batched convolutions may pick another
+    algorithm), a bad image fails only its own caller, and the counters show that calls were combined."""
+    import threading
+
+    import torch
+
+    rng = np.random.default_rng(8)
+    imgs = [rng.integers(0, 256, (40 + 8 * i, 56, 3), dtype=np.uint8) for i in range(6)]
+    alone = [cnn.describe(im) for im in imgs]
+    assert all(a.shape == (2048,) and not a.is_cuda for a in alone)
+    before = (cnn.combined_batches, cnn.combined_calls)
+    assert before == (0, 0)                      # one caller at a time: nothing to combine
+    out, errors = {}, {}
+    start = threading.Barrier(len(imgs) + 1)
+
+    def work(i, image):
+        start.wait()
+        try:
+            out[i] = [cnn.describe(image) for _ in range(2)]
+        except Exception as e:
+            errors[i] = e
+
+    th = [threading.Thread(target=work, args=(i, im)) for i, im in enumerate(imgs)]
+    th.append(threading.Thread(target=work, args=("bad", np.zeros((8, 8), np.uint8))))
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert list(errors) == ["bad"] and isinstance(errors["bad"], ValueError)
+    for i, a in enumerate(alone):
+        for f in out[i]:
+            assert f.shape == (2048,) and torch.allclose(f, a, rtol=1e-3, atol=1e-3 * float(a.abs().max()))
+    assert cnn.combined_batches >= 1 and cnn.combined_calls >= 2 * cnn.combined_batches

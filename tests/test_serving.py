@@ -11,6 +11,7 @@ import json
 import numpy as np
 import pytest
 
+from image_search_engine_amd.config import Config
 from oracle import knn_oracle as ko
 
 
@@ -127,7 +128,7 @@ def test_describe_dataset_tracks_the_paths_it_described(tmp_path, monkeypatch):
     """A skipped image leaves no row: described_paths[i] is the path of row i (quirk 5.9-4)."""
     from image_search_engine_amd import descriptors as ds
 
-    monkeypatch.setattr(ds.config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib")
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib")
     rng = np.random.default_rng(1)
     paths = _write_images(tmp_path / "data", 9, rng, size=16)
     paths[4].write_bytes(b"broken")                       # undecodable -> printed and skipped
@@ -192,10 +193,11 @@ def test_indexer_engine_route_end_to_end_on_gpu(tmp_path, monkeypatch):
     paths = _write_images(data, 40, rng, size=64)
     (data / "img_0005.png").write_bytes(b"broken")       # skipped at index time
     models = tmp_path / "models"
-    for mod in (ds, engine, indexer, utils):
-        monkeypatch.setattr(mod.config, "DATA_FOLDER_PATH", data, raising=False)
-        monkeypatch.setattr(mod.config, "DNN_INDEX_PATH", models / "resnet50_dnn_index.faiss", raising=False)
-        monkeypatch.setattr(mod.config, "BOVW_CORNER_DESCRIPTIONS_PATH", models / "absent.joblib", raising=False)
+    # the class, not the modules' instances: patching an instance would leave an attribute behind that
+    # shadows the class for every later test
+    monkeypatch.setattr(Config, "DATA_FOLDER_PATH", data)
+    monkeypatch.setattr(Config, "DNN_INDEX_PATH", models / "resnet50_dnn_index.faiss")
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", models / "absent.joblib")
     index = indexer.main()
     assert index.ntotal == 39
     listed = json.loads(engine.paths_file_for(models / "resnet50_dnn_index.faiss").read_text())
@@ -226,7 +228,7 @@ def test_process_pool_decoder_gives_the_same_descriptions(tmp_path, monkeypatch)
 
     from image_search_engine_amd import descriptors as ds
 
-    monkeypatch.setattr(ds.config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib", raising=False)
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib")
     rng = np.random.default_rng(3)
     paths = _write_images(tmp_path / "data", 23, rng, size=24)
     paths += _write_images(tmp_path / "data2", 6, rng, size=40)      # 4800 B each: larger than the small slots below
@@ -235,8 +237,8 @@ def test_process_pool_decoder_gives_the_same_descriptions(tmp_path, monkeypatch)
     outs = {}
     for name, procs, slot_bytes in (("threads", 0, 3 << 20), ("ring", 3, 3 << 20), ("small slots", 3, 2048),
                                     ("no ring", 3, 0)):
-        monkeypatch.setattr(ds.config, "DECODE_PROCESSES", procs, raising=False)
-        monkeypatch.setattr(ds.config, "DECODE_SLOT_BYTES", slot_bytes, raising=False)
+        monkeypatch.setattr(Config, "DECODE_PROCESSES", procs)
+        monkeypatch.setattr(Config, "DECODE_SLOT_BYTES", slot_bytes)
         describer = ds.Describer({"conv_features": _MeanColourDescriptor()}, batch_size=5)
         out = ds.describe_dataset(describer, arr)
         outs[name] = (np.concatenate([np.asarray(o) for o in out]), list(describer.described_paths))
@@ -259,8 +261,8 @@ def test_describer_collects_async_batches_in_order(tmp_path, monkeypatch):
     and the last batch is collected at the end."""
     from image_search_engine_amd import descriptors as ds
 
-    monkeypatch.setattr(ds.config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib", raising=False)
-    monkeypatch.setattr(ds.config, "DECODE_PROCESSES", 0, raising=False)
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib")
+    monkeypatch.setattr(Config, "DECODE_PROCESSES", 0)
     rng = np.random.default_rng(4)
     paths = _write_images(tmp_path / "data", 22, rng, size=16)
     events = []
