@@ -58,6 +58,7 @@ class Config:
     DNN_BATCH_SIZE = 64                     # images per forward pass (the reference runs batch 1)
     DECODE_WORKERS = 8                      # threads decoding images ahead of the GPU batches
     DECODE_PROCESSES = 0                    # > 0: decode in that many spawned processes instead (past ~2 k images/s)
+    CNN_GRAPHS = True                       # batches of 1, 2, 4 ... 32 images replay a captured HIP graph of the network
     DESCRIBE_COMBINE_MAX = 32               # concurrent describe() calls share one forward pass of up to this many images (0: never)
     DESCRIBE_ASYNC = True                   # launch batch i + 1 on the device before collecting batch i
     DECODE_SLOT_BYTES = 3 << 20             # decode processes hand pixels over in /dev/shm slots of this size (0: pickle them)

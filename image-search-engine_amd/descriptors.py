@@ -93,6 +93,7 @@ class CNNDescriptor:
         self._stage = {"bufs": [None, None], "events": [None, None], "turn": 0}
         self._stage_lock = threading.Lock()  # Flask request threads share one descriptor
         self._init_combining()
+        self._graphs, self._graph_lock = {}, threading.Lock()
         self.initialize_model()
 
     def _init_combining(self):
@@ -101,7 +102,7 @@ class CNNDescriptor:
 
     def __getstate__(self):  # copies and pickles leave the staging buffers and their lock behind
         d = dict(self.__dict__)
-        for name in ("_stage", "_stage_lock", "_cq", "_cq_leader", "_cq_lock"):
+        for name in ("_stage", "_stage_lock", "_cq", "_cq_leader", "_cq_lock", "_graphs", "_graph_lock"):
             d.pop(name, None)
         return d
 
@@ -110,6 +111,7 @@ class CNNDescriptor:
         self._stage = {"bufs": [None, None], "events": [None, None], "turn": 0}
         self._stage_lock = threading.Lock()
         self._init_combining()
+        self._graphs, self._graph_lock = {}, threading.Lock()
         if getattr(self.preprocessor, "__self__", None) is not None:
             self.preprocessor = self._preprocess_batch
 
@@ -204,7 +206,7 @@ class CNNDescriptor:
         x = (x - self._mean) / self._std  # (img - mean*255) / (std*255), channel order untouched
         return x.contiguous(memory_format=torch.channels_last)
 
-    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward_eager(self, x: torch.Tensor) -> torch.Tensor:
         if self.dtype != torch.float32:
             with torch.autocast(self.device.type, dtype=self.dtype):
                 f = self.feature_extractor(x).float()
@@ -213,6 +215,47 @@ class CNNDescriptor:
         if self.projection is not None:
             f = f @ self.projection
         return f
+
+    GRAPH_BATCHES = (1, 2, 4, 8, 16, 32)
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Small batches replay a captured HIP graph of the network (one per batch size in GRAPH_BATCHES,
+        captured at first use): at one image the eager forward is 2.4 ms of launches for 0.3 ms of device
+        work -- the request path of backend/engine.py:78 lives there.  Larger batches are device-bound
+        and run eagerly.  ``config.CNN_GRAPHS = False`` turns the graphs off."""
+        b = x.shape[0]
+        if x.is_cuda and b in self.GRAPH_BATCHES and getattr(config, "CNN_GRAPHS", True) and not torch.is_grad_enabled():
+            with self._graph_lock:   # a graph's input and output buffers are its own: one replay at a time
+                g = self._graphs.get(b)
+                if g is None and b not in self._graphs:
+                    g = self._graphs[b] = self._capture(b)
+                if g is not None:
+                    graph, x_static, out_static = g
+                    x_static.copy_(x)
+                    graph.replay()
+                    return out_static.clone()
+        return self._forward_eager(x)
+
+    def _capture(self, b: int):
+        """(graph, input buffer, output buffer) of one batch size, or None when capture is refused."""
+        try:
+            x_static = torch.zeros((b, 3, config.RESIZE_SIZE, config.RESIZE_SIZE), device=self.device).contiguous(
+                memory_format=torch.channels_last)
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):      # the convolution library picks its kernels here, not in the capture
+                for _ in range(3):
+                    self._forward_eager(x_static)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out_static = self._forward_eager(x_static)
+            return graph, x_static, out_static
+        except Exception as e:  # noqa: BLE001 -- eager is always there
+            print(f"NOTE: no HIP graph for batches of {b} ({e.__class__.__name__}: {e}); running them eagerly")
+            return None
 
     # -- batched entry points (new capability)
     @torch.no_grad()

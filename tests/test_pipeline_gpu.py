@@ -55,6 +55,57 @@ def test_batched_preprocess_equals_the_one_image_path():
         gpu.preprocessor([np.zeros((8, 8), np.uint8)])
 
 
+def test_small_batches_replay_a_graph_of_the_network(monkeypatch):
+    """Batches of 1, 2, 4 ... 32 images go through a captured HIP graph (descriptors.CNNDescriptor._forward):
+    same features as the eager network, for float32 and for bf16 autocast, replay after replay with
+    different inputs, from several threads; other batch sizes and config.CNN_GRAPHS = False run eagerly."""
+    import threading
+
+    from image_search_engine_amd.config import Config
+    from image_search_engine_amd.descriptors import CNNDescriptor
+
+    rng = np.random.default_rng(6)
+    for dtype, tol in ((torch.bfloat16, 2e-2), (torch.float32, 1e-4)):   # the float32 one serves the thread part below
+        gpu = CNNDescriptor(device="cuda", dtype=dtype)
+        for b in (1, 2, 3, 8, 32):
+            imgs = [rng.integers(0, 256, (224, 224, 3), dtype=np.uint8) for _ in range(b)]
+            with torch.no_grad():
+                x = gpu.preprocessor(imgs)
+                want = gpu._forward_eager(x)
+                got = [gpu._forward(x).clone() for _ in range(2)]
+                again = gpu._forward(gpu.preprocessor(imgs[::-1]))   # the same graph, other pixels
+            scale = float(want.abs().max())
+            for g in got:
+                assert torch.allclose(g, want, rtol=tol, atol=tol * scale), (dtype, b)
+            assert torch.allclose(again.flip(0), want, rtol=tol, atol=tol * scale)
+            assert (b in gpu._graphs and gpu._graphs[b] is not None) == (b in gpu.GRAPH_BATCHES), (b, list(gpu._graphs))
+    # threads replaying the batch-1 graph at once each get their own image's features
+    yy, xx = np.mgrid[0:224, 0:224]
+    imgs = [np.stack([(xx * (i + 1)) % 256, (yy * (8 - i)) % 256, np.full_like(xx, 30 * i)], -1).astype(np.uint8)
+            for i in range(8)]                                  # structured and pairwise different
+    monkeypatch.setattr(Config, "DESCRIBE_COMBINE_MAX", 0)   # every describe() is its own forward pass here
+    want = [gpu.describe(im) for im in imgs]
+    scale = max(float(w.abs().max()) for w in want)
+    close = lambda a, b: torch.allclose(a, b, rtol=1e-3, atol=1e-3 * scale)  # noqa: E731 -- replays of one graph
+    again = [gpu.describe(im) for im in imgs]
+    assert all(close(a, w) for a, w in zip(again, want)), [float((a - w).abs().max()) / scale for a, w in zip(again, want)]
+    assert not any(close(want[i], want[j]) for i in range(8) for j in range(i))   # a mix-up would show
+    out = {}
+
+    def work(i):
+        out[i] = [gpu.describe(imgs[i]) for _ in range(5)]
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    bad = [(i, float((f - want[i]).abs().max())) for i in range(8) for f in out[i] if not close(f, want[i])]
+    assert not bad, (bad, scale)
+    monkeypatch.setattr(Config, "CNN_GRAPHS", False)
+    eager = CNNDescriptor(device="cuda", dtype=torch.bfloat16)
+    assert torch.allclose(eager.describe(imgs[0]), want[0], rtol=2e-2, atol=2e-2 * float(want[0].abs().max()))
+    assert eager._graphs == {}
+
+
 def test_indexer_then_engine_roundtrip(tmp_path, monkeypatch):
     from PIL import Image
 
