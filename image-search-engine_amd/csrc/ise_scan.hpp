@@ -501,7 +501,7 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
             }
             load_b(bnext, s + 1 < CH ? s0 + s + 1 : next_first_step);
             f32x4 as = a[s];
-            if (SHIFT) as = as - *reinterpret_cast<const f32x4*>(mus + 4 * g + 16 * (s0 + s));
+            if (SHIFT && !ABL(1024)) as = as - *reinterpret_cast<const f32x4*>(mus + 4 * g + 16 * (s0 + s));
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 if (BF16) {  // one 16x16x32 bf16 MFMA per k-step (8 bf16 per lane and operand)
