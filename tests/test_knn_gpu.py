@@ -584,3 +584,57 @@ def test_streams_and_threads_stress_with_exchange(faiss):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errors, errors
+
+
+@pytest.mark.parametrize("storage,metric", [("f32", 1), ("bf16", 0)])
+def test_ten_million_rows_on_one_gpu(faiss, storage, metric):
+    """BASELINE config 5's row count on ONE card (20.5 GB float32 / 10.2 GB bf16): every offset in the
+    library is 64-bit clean.  The CPU oracle does not finish this size in seconds, so the checker here is a
+    float64 brute force in torch on the device, chunk by chunk (rows are regenerated from per-chunk seeds);
+    float32 L2 ids must be identical, bf16 ids identical on the rounded values the index holds."""
+    import torch
+
+    dev = torch.device("cuda")
+    N, d, nq, k, CH = 10_000_000, 512, 16, 10, 1_000_000
+    unit = storage == "bf16"
+
+    def chunk(i):
+        g = torch.Generator(device=dev).manual_seed(1000 + i)
+        x = torch.rand((CH, d), generator=g, device=dev)
+        if unit:
+            x = x - 0.5
+            x = x / x.norm(dim=1, keepdim=True)
+        return x
+
+    index = faiss.IndexFlat(d, metric, storage=storage)
+    for i in range(N // CH):
+        index.add_torch(chunk(i))
+    assert index.ntotal == N
+    g = torch.Generator(device=dev).manual_seed(7)
+    xq = torch.rand((nq, d), generator=g, device=dev)
+    if unit:
+        xq = xq - 0.5
+        xq = xq / xq.norm(dim=1, keepdim=True)
+    xq[3] = chunk(9)[CH - 1]                       # the very last row is its own nearest neighbour
+    D, I = index.search_torch(xq, k)
+    best_d = torch.full((nq, k), float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
+    q64 = xq.to(torch.bfloat16).double() if unit else xq.double()
+    for i in range(N // CH):
+        x = chunk(i)
+        x64 = x.to(torch.bfloat16).double() if unit else x.double()
+        if metric == 1:
+            s = (q64 * q64).sum(1, keepdim=True) + (x64 * x64).sum(1)[None, :] - 2.0 * q64 @ x64.T
+        else:
+            s = -(q64 @ x64.T)
+        ids = torch.arange(i * CH, (i + 1) * CH, device=dev)[None, :].expand(nq, -1)
+        cd, ci = torch.cat([best_d, s], 1), torch.cat([best_i, ids], 1)
+        o = torch.argsort(cd, dim=1, stable=True)[:, :k]
+        best_d, best_i = torch.gather(cd, 1, o), torch.gather(ci, 1, o)
+        del x, x64, s
+    assert I[3, 0].item() == N - 1
+    assert torch.equal(I, best_i), (I != best_i).nonzero()[:5]
+    got = D.double() if metric == 1 else -D.double()
+    assert float((got - best_d).abs().max()) <= 1e-4
+    del index
+    torch.cuda.empty_cache()
