@@ -90,6 +90,57 @@ def pmc_traffic(n, d, nq, k, world):
     return rec["scan_kernel"]["traffic_bytes_per_launch"]
 
 
+class BoardPower:
+    """Board power of the card this rank runs on, read from the amdgpu hwmon files while the steps run
+    (a thread, one read per 10 ms; no GPU API involved).  The one-tile scan runs at the board's power cap
+    (DESIGN.md 5): this is the evidence for the run the line comes from.  Everything here is best effort:
+    unreadable files give ``None``."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+
+        self.samples, self.cap, self._stop, self._thread, self._file = [], None, False, None, None
+        try:
+            bus = int(torch.cuda.get_device_properties(device_index).pci_bus_id)
+            for c in glob.glob("/sys/class/drm/card*/device"):
+                addr = os.path.basename(os.path.realpath(c))
+                if addr.count(":") == 2 and int(addr.split(":")[1], 16) == bus:
+                    hw = sorted(glob.glob(os.path.join(c, "hwmon", "hwmon*")))
+                    if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                        self._file = os.path.join(hw[0], "power1_input")
+                        capf = os.path.join(hw[0], "power1_cap")
+                        if os.path.exists(capf):
+                            with open(capf) as f:
+                                self.cap = float(f.read()) / 1e6
+            if self._file:
+                self._thread = threading.Thread(target=self._run, daemon=True)
+                self._thread.start()
+        except Exception:  # noqa: BLE001
+            self._file = None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                with open(self._file) as f:
+                    self.samples.append((time.perf_counter(), float(f.read()) / 1e6))
+            except Exception:  # noqa: BLE001
+                pass
+            time.sleep(0.01)
+
+    def stop(self, t_from):
+        """mean / max of the samples taken since ``t_from`` (perf_counter), or None."""
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+        v = [w for t, w in self.samples if t >= t_from]
+        if not v:
+            return None
+        return {"mean_w": round(sum(v) / len(v), 1), "max_w": round(max(v), 1), "cap_w": self.cap, "samples": len(v),
+                "what": "hwmon power1_input of this card, one read per 10 ms over the last 0.8 s of 2 s of the same "
+                        "steps issued back to back after the timed region (the reading is a moving average)"}
+
+
 def cpu_baseline(xb, xq, k, budget_s=12.0):
     """Faiss-equivalent CPU restatement (oracle/flat_oracle.c, kind 'port') timed on this
     host's cores on a bounded sample: the same query batch against the first `rows` index
@@ -281,6 +332,16 @@ def main():
         us = np.sort(np.array([e0.elapsed_time(e1) * 1e3 for e0, e1 in evs]))
         latency = {"p10": float(us[10]), "median": float(us[50]), "p90": float(us[90]),
                    "what": "one batch at a time on one stream: scan + merge, HIP event pair per batch, 100 batches"}
+    # board power under the same steps, sustained (untimed, after everything that is timed): the hwmon figure is
+    # a moving average that needs about a second of load to settle, the K timed steps are over in milliseconds
+    board_power = None
+    if not sharded and nq <= 64:
+        power = BoardPower(dev.index if dev.index is not None else 0)
+        t_seg = time.perf_counter()
+        while time.perf_counter() - t_seg < 2.0:
+            run(200)
+            torch.cuda.synchronize()
+        board_power = power.stop(t_seg + 1.2)
 
     if rank == 0:
         res = {
@@ -312,7 +373,7 @@ def main():
                          else achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n, d, nq, k, world),
                          "kernel": "gemm_scan_kernel (threshold sample + main pass)" if gemm_batch else "scan_kernel",
-                         "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
+                         "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms, "board_power": board_power,
                          "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
                          # the same bytes over the measured step time (batches overlapped on the GPU):
                          # what the whole step sustains, beside the isolated kernel's figure above
