@@ -10,6 +10,7 @@ from __future__ import annotations
 import mmap
 import os
 import tempfile
+import weakref
 
 import numpy as np
 
@@ -51,6 +52,8 @@ class SlotRing:
         os.close(fd)
         self.nslots, self.slot_bytes = nslots, slot_bytes
         self.buf = np.frombuffer(self.map, dtype=np.uint8)
+        # the file must not outlive the process even when close() is never reached (finalizers also run at exit)
+        self._unlink = weakref.finalize(self, _unlink_quiet, self.path)
 
     def view(self, slot: int, shape) -> np.ndarray:
         """The pixels a worker left in ``slot`` (no copy: valid until the slot is handed out again)."""
@@ -65,13 +68,17 @@ class SlotRing:
                 self.map.close()
             except BufferError:  # a view is still alive somewhere: the mapping goes with it
                 pass
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+            self._unlink()
 
     def __del__(self):
         self.close()
+
+
+def _unlink_quiet(path: str) -> None:
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
 
 
 _ring = {}  # worker side: path -> (mmap, uint8 view); one entry per pool lifetime
