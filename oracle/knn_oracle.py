@@ -185,6 +185,44 @@ def assign_nearest(X, centroids, metric: int = METRIC_INNER_PRODUCT) -> np.ndarr
     return I
 
 
+def lloyd_reference(x, c0, niter: int, spherical: bool = False):
+    """float64 restatement of the k-means iteration Faiss's ``Clustering::train`` runs from given initial
+    centroids [upstream-faiss Clustering.cpp; the reference reaches it through ``faiss.Kmeans(...).train``,
+    backend/kmeans_faiss.py:29-44]: per iteration assign every row to its nearest centroid (spherical: largest
+    inner product with unit centroids), record the objective (``Kmeans.obj``: summed squared distances, or
+    summed inner products), replace every centroid by the mean of its rows (spherical: renormalised).  Faiss
+    re-seeds EMPTY clusters by splitting large ones with its own RNG -- not restated: an empty cluster raises.
+    Returns (centroids float64 (k, d), objective per iteration, labels of the last assignment)."""
+    x64 = np.asarray(x, dtype=np.float64)
+    c = np.asarray(c0, dtype=np.float64).copy()
+    k = c.shape[0]
+    obj, lab = [], None
+
+    def unit(a):
+        nrm = np.linalg.norm(a, axis=1, keepdims=True)
+        return np.where(nrm > 0, a / np.where(nrm > 0, nrm, 1.0), a)
+
+    for _ in range(int(niter)):
+        if spherical:
+            c = unit(c)
+            s = x64 @ c.T
+            lab = np.argmax(s, axis=1)          # ties: lowest centroid id, as the index search returns
+            obj.append(float(s[np.arange(len(lab)), lab].sum()))
+        else:
+            d2 = (x64 * x64).sum(1, keepdims=True) + (c * c).sum(1)[None, :] - 2.0 * (x64 @ c.T)
+            lab = np.argmin(d2, axis=1)
+            obj.append(float(np.maximum(d2[np.arange(len(lab)), lab], 0.0).sum()))
+        cnt = np.bincount(lab, minlength=k)
+        if (cnt == 0).any():
+            raise ValueError("empty cluster: Faiss's re-seeding is not restated")
+        sums = np.zeros_like(c)
+        np.add.at(sums, lab, x64)
+        c = sums / cnt[:, None]
+    if spherical:
+        c = unit(c)
+    return c, obj, lab
+
+
 def merge_shards(D_parts, I_parts, k: int, metric: int = METRIC_L2):
     """Merge per-shard (D, I) lists (ids already global) under (score, id) order.
     Restates what one all-gather + merge must produce."""

@@ -112,3 +112,28 @@ def test_key_codec_is_order_preserving():
     o = kc.ord_f32(v).astype(np.int64)
     assert (np.diff(o) >= 0).all() and (np.diff(o)[[0, 1, 2, 4, 5, 6, 7]] > 0).all()
     assert np.array_equal(kc.unord_f32(kc.ord_f32(v)).view(np.uint32), v.view(np.uint32))
+
+
+def test_lloyd_reference_against_sklearn():
+    """The oracle's k-means iteration (what the GPU trainer is compared with) against an independent
+    implementation: sklearn's Lloyd from the same initial centroids, the same number of iterations."""
+    pytest.importorskip("sklearn")
+    from sklearn.cluster import KMeans
+
+    rng = np.random.default_rng(3)
+    K, d, per = 9, 12, 120
+    centres = rng.standard_normal((K, d)) * 6.0
+    x = np.concatenate([centres[i] + rng.standard_normal((per, d)) for i in range(K)]).astype(np.float32)
+    c0 = (centres + rng.standard_normal((K, d)) * 1.5).astype(np.float32)
+    for niter in (1, 4):
+        c, obj, lab = ko.lloyd_reference(x, c0, niter)
+        sk = KMeans(n_clusters=K, init=c0.astype(np.float64), n_init=1, max_iter=niter, tol=0.0, algorithm="lloyd")
+        sk.fit(x.astype(np.float64))
+        np.testing.assert_allclose(c, sk.cluster_centers_, rtol=1e-9, atol=1e-9)
+        assert len(obj) == niter and all(a >= b - 1e-9 for a, b in zip(obj, obj[1:]))   # never increases
+    # spherical: unit centroids, objective = summed inner products, never decreases
+    cs, objs, _ = ko.lloyd_reference(x, c0, 5, spherical=True)
+    np.testing.assert_allclose(np.linalg.norm(cs, axis=1), 1.0, rtol=1e-12)
+    assert all(b >= a - 1e-9 for a, b in zip(objs, objs[1:]))
+    with pytest.raises(ValueError, match="empty cluster"):
+        ko.lloyd_reference(x, np.concatenate([c0[:-1], c0[-1:] * 0 + 1e6]), 2)

@@ -211,6 +211,35 @@ def test_kmeans_train_lloyd_on_gpu():
     assert len(set(I.ravel().tolist())) == K
 
 
+@pytest.mark.parametrize("spherical", [False, True])
+def test_kmeans_train_matches_the_oracle_iteration(spherical):
+    """from given initial centroids (``init_centroids``, backend/kmeans_faiss.py:41) the trainer's
+    iterations are the oracle's float64 Lloyd iterations (oracle/knn_oracle.py::lloyd_reference, itself checked
+    against sklearn in tests/test_oracle.py): same centroids, same objective per iteration (``Kmeans.obj``),
+    same final assignment -- also at the size where the MFMA assignment kernel takes over (n >= 2048).  What
+    stays unpinned is Faiss's own seeding and its re-seeding of empty clusters (neither occurs here)."""
+    import image_search_engine_amd.faiss_compat as faiss
+    from oracle import knn_oracle as ko
+
+    rng = np.random.default_rng(21)
+    K, d, per = 24, 48, 150                     # n = 3600: the k = 1 assignment kernel runs the E-step
+    centres = rng.standard_normal((K, d)) * 4.0
+    x = np.concatenate([centres[i] + rng.standard_normal((per, d)) for i in range(K)]).astype(np.float32)
+    c0 = (centres + rng.standard_normal((K, d)) * 0.8).astype(np.float32)
+    niter = 6
+    km = faiss.Kmeans(d=d, k=K, niter=niter, nredo=1, seed=5, spherical=spherical)
+    last = km.train(x, init_centroids=c0)
+    c_ref, obj_ref, lab_ref = ko.lloyd_reference(x, c0, niter, spherical=spherical)
+    np.testing.assert_allclose(km.centroids, c_ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(km.obj, obj_ref, rtol=2e-5)
+    assert km.obj.shape == (niter,) and abs(last - obj_ref[-1]) <= 2e-5 * abs(obj_ref[-1])
+    # the index the reference then searches (kmeans_faiss.py:49) holds those centroids
+    _, I = km.index.search(x, 1)
+    c_fin = c_ref
+    want = ko.assign_nearest(x, c_fin.astype(np.float32), ko.METRIC_INNER_PRODUCT if spherical else ko.METRIC_L2)
+    assert (I.ravel() == np.asarray(want).ravel()).mean() > 0.999   # rows on a cell boundary may flip at 1e-5
+
+
 def test_query_index_both_branches_match_reference_formulas():
     """backend/siamese/test_index.py:49-71: faiss branch = normalise + IP search; dict branch =
     normalise + per-row np.linalg.norm + argsort (non-squared L2, returns (indices, distances))."""
