@@ -301,3 +301,38 @@ def test_describer_collects_async_batches_in_order(tmp_path, monkeypatch):
     # batch i is collected after batch i + 1 has been launched; the failed launch has no result() call
     assert events == [("launch", 0), ("launch", 1), ("result", 0), ("launch", 2), ("launch", 3), ("result", 2),
                       ("launch", 4), ("result", 3), ("result", 4)]
+
+
+@pytest.mark.gpu
+def test_process_pool_feed_on_the_gpu_equals_the_thread_pool(tmp_path, monkeypatch):
+    """The whole feed on the MI355X -- decode processes, /dev/shm pixel slots, one pinned upload per batch,
+    batch i + 1 launched before batch i is collected -- describes mixed-size files exactly as the plain
+    thread-pool, collect-at-once configuration does: same rows, same order, same skipped files."""
+    import torch
+
+    from image_search_engine_amd import descriptors as ds
+
+    assert torch.cuda.is_available()
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib")
+    rng = np.random.default_rng(9)
+    paths = []
+    for j, size in enumerate((48, 64, 48, 80)):
+        paths += _write_images(tmp_path / f"d{j}", 11, rng, size=size)
+    paths[5].write_bytes(b"broken")
+    arr = np.array(paths).reshape(-1, 1)
+    desc = ds.CNNDescriptor()
+    outs = {}
+    for name, procs, asyn in (("threads, collect at once", 0, False), ("processes, async", 3, True),
+                              ("threads, async", 0, True)):
+        monkeypatch.setattr(Config, "DECODE_PROCESSES", procs)
+        monkeypatch.setattr(Config, "DESCRIBE_ASYNC", asyn)
+        describer = ds.Describer({"conv_features": desc}, batch_size=8)
+        out = ds.describe_dataset(describer, arr)
+        outs[name] = (np.concatenate([np.asarray(o) for o in out]), list(describer.described_paths))
+        describer.close()
+    ref = outs["threads, collect at once"]
+    assert ref[0].shape == (43, 2048) and len(ref[1]) == 43
+    for name in ("processes, async", "threads, async"):
+        assert outs[name][1] == ref[1], name
+        # same batches through the same network; the convolution library's kernels are not bitwise repeatable
+        assert np.allclose(outs[name][0], ref[0], rtol=1e-4, atol=1e-4 * float(np.abs(ref[0]).max())), name
