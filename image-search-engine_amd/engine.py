@@ -93,7 +93,7 @@ def run_image_queries(features, n_images, normalize=False):
 
 def create_app():
     """POST /similar_images, multipart field ``image`` -> {"prediction": [[dist, b64, path], ...]}
-    (backend/engine.py:68-107; frontend/src/App.js:14-21)."""
+    (backend/engine.py:68-107; frontend/src/App.js:14-21); POST /similar_images_batch for several files."""
     import io
 
     from flask import Flask, Response, request
@@ -122,5 +122,30 @@ def create_app():
         predictions = run_image_query(image_features, config.NUM_IMAGES_TO_RETURN)
         print(f"Took {time.time() - start:.2f} seconds.")
         return Response(response=json.dumps({"prediction": predictions}), status=200, mimetype="application/json")
+
+    @app.route("/similar_images_batch", methods=["POST"])
+    def predict_batch():
+        """Several uploads in one request: the multipart field ``image`` repeated ->
+        {"predictions": [prediction list of upload 0, of upload 1, ...]}, each list exactly what
+        /similar_images returns for that file -- one batched forward pass, one index.search."""
+        files = request.files.getlist("image") if request.files else []
+        if not files:
+            return Response("No file uploaded", status=400)
+        if config.METHOD != Method.DNN:
+            return Response("only METHOD=DNN is served", status=501)
+        images = []
+        for f in files:
+            try:
+                rgb = np.asarray(Image.open(io.BytesIO(f.read())).convert("RGB"))
+            except Exception:
+                return Response(f"Not an image: {f.filename}", status=400)
+            images.append(np.ascontiguousarray(rgb[:, :, ::-1]))
+        if hasattr(descriptor, "describe_batch"):
+            feats = descriptor.describe_batch(images)
+        else:
+            feats = [descriptor.describe(im) for im in images]
+        feats = np.stack([np.asarray(f, dtype=np.float32).reshape(-1) for f in feats])
+        predictions = run_image_queries(feats, config.NUM_IMAGES_TO_RETURN)
+        return Response(response=json.dumps({"predictions": predictions}), status=200, mimetype="application/json")
 
     return app

@@ -105,6 +105,32 @@ def test_similar_images_wire_format(served):
     assert np.allclose([p[0] for p in pred], D_ref[0])
 
 
+def test_similar_images_batch_endpoint(served):
+    """/similar_images_batch: the field ``image`` repeated; every upload gets exactly the list /similar_images
+    returns for it (one batched search behind it); 400 without files or with a non-image among them."""
+    engine, paths, feats = served
+    client = engine.create_app().test_client()
+    from PIL import Image
+
+    probes = [3, 11, 3]
+    uploads = [(io.BytesIO(_png_bytes(np.asarray(Image.open(paths[i]).convert("RGB")))), f"q{j}.png")
+               for j, i in enumerate(probes)]
+    resp = client.post("/similar_images_batch", data={"image": uploads}, content_type="multipart/form-data")
+    assert resp.status_code == 200 and resp.mimetype == "application/json"
+    body = json.loads(resp.data)
+    assert list(body.keys()) == ["predictions"] and len(body["predictions"]) == 3
+    for i, pred in zip(probes, body["predictions"]):
+        rgb = np.asarray(Image.open(paths[i]).convert("RGB"))
+        one = client.post("/similar_images", data={"image": (io.BytesIO(_png_bytes(rgb)), "q.png")},
+                          content_type="multipart/form-data")
+        assert pred == json.loads(one.data)["prediction"]
+        assert pred[0][2] == str(paths[i]) and pred[0][0] == 0.0
+    assert client.post("/similar_images_batch").status_code == 400
+    bad = client.post("/similar_images_batch", content_type="multipart/form-data",
+                      data={"image": [(io.BytesIO(_png_bytes(rgb)), "ok.png"), (io.BytesIO(b"nope"), "bad.png")]})
+    assert bad.status_code == 400 and b"bad.png" in bad.data
+
+
 def test_similar_images_errors_and_missing_files(served):
     engine, paths, feats = served
     client = engine.create_app().test_client()
