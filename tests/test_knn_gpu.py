@@ -638,3 +638,34 @@ def test_ten_million_rows_on_one_gpu(faiss, storage, metric):
     assert float((got - best_d).abs().max()) <= 1e-4
     del index
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_config4_full_size_assignment(faiss, metric):
+    """BASELINE config 4 at its full size on one card: 50k images x 1k keypoints = 50 M SIFT-valued rows x 128
+    against 4096 unit centroids, k = 1 (backend/kmeans_faiss.py:46-50 behind
+    backend/bag_of_visual_words.py:98-106), generated on the device in chunks of 5 M rows as SURVEY.md 8d
+    prescribes.  Every label is in range, and a 1500-row sample of every chunk is checked against the float64
+    oracle (ids identical away from float32 near-ties)."""
+    import torch
+
+    K, d, chunk, nchunks = 4096, 128, 5_000_000, 10
+    rng = np.random.default_rng(42)
+    cent = ko.normalize_rows(rng.standard_normal((K, d)).astype(np.float32))
+    index = make_index(faiss, metric, d)
+    index.add(cent)
+    assert index._assign_applies(chunk, 1)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    total = 0
+    for i in range(nchunks):
+        X = torch.randint(0, 256, (chunk, d), generator=g, device="cuda", dtype=torch.int32).to(torch.float32)
+        D, I = index.assign_torch(X)
+        assert I.shape == (chunk, 1) and int(I.min()) >= 0 and int(I.max()) < K
+        total += chunk
+        pick = torch.randint(0, chunk, (1500,), generator=g, device="cuda")
+        xs = X[pick].cpu().numpy()
+        D_ref, I_ref = ko.knn_exact(cent, xs, 1, metric)
+        assert_knn_matches(D[pick].cpu().numpy(), I[pick].cpu().numpy(), D_ref, I_ref, cent, xs, metric,
+                           gap=ko.kth_gap(cent, xs, 1, metric), rtol=2e-4)
+        del X, D, I
+    assert total == 50_000_000
