@@ -408,3 +408,35 @@ def test_config2_cnn_embeddings_to_l2_index_end_to_end():
     assert I0[0, 0] == 17 and D0[0, 0] == 0.0
     st = index.exact_stats()
     assert st["reranked"] == nq + 1
+
+
+def test_config2_at_full_size():
+    """BASELINE config 2 at its full size: 100 000 seeded synthetic images -> seeded random-init ResNet-50
+    (out_dim = 512) -> L2 index -> k = 10 search, nq = 1, 16 and 1024, ids against the C oracle on the very
+    embeddings the index holds (the float64 numpy oracle covers the 16-query batch as well)."""
+    from image_search_engine_amd.descriptors import CNNDescriptor
+    from image_search_engine_amd.utils import create_search_index
+    from oracle import flat_oracle as fo
+    from oracle import knn_oracle as ko
+    from tests.knn_checks import assert_knn_matches
+
+    n, d, k = 100_000, 512, 10
+    desc = CNNDescriptor(out_dim=d, seed=0)
+    g = torch.Generator(device="cuda").manual_seed(99)
+    feats = []
+    for i0 in range(0, n + 1024, 512):
+        imgs = torch.randint(0, 256, (min(512, n + 1024 - i0), 224, 224, 3), generator=g, device="cuda",
+                             dtype=torch.uint8)
+        feats.append(desc.extract_features_tensor(imgs).cpu())
+    feats = torch.cat(feats).numpy()
+    xb, xq = np.ascontiguousarray(feats[:n]), np.ascontiguousarray(feats[n:])
+    assert xb.shape == (n, d) and xq.shape == (1024, d) and np.isfinite(feats).all()
+    index = create_search_index(xb.copy(), index_type="l2")
+    assert index.ntotal == n
+    for nq in (1, 16, 1024):
+        D, I = index.search(xq[:nq], k)
+        D_ref, I_ref, _ = fo.knn_flat(xb, xq[:nq], k, ko.METRIC_L2, 16)
+        assert_knn_matches(D, I, D_ref, I_ref, xb, xq[:nq], ko.METRIC_L2)
+    D64, I64 = ko.knn_exact(xb, xq[:16], k, ko.METRIC_L2)
+    D, I = index.search(xq[:16], k)
+    assert assert_knn_matches(D, I, D64, I64, xb, xq[:16], ko.METRIC_L2, gap=ko.kth_gap(xb, xq[:16], k, ko.METRIC_L2)) == 0
