@@ -636,6 +636,30 @@ def test_ten_million_rows_on_one_gpu(faiss, storage, metric):
     assert torch.equal(I, best_i), (I != best_i).nonzero()[:5]
     got = D.double() if metric == 1 else -D.double()
     assert float((got - best_d).abs().max()) <= 1e-4
+    if unit:
+        # what BASELINE config 5 reports: recall@10 of the bf16 index against the float32-exact answer, on a
+        # 1000-query sample (float64 brute force on the UNROUNDED rows; the large-batch bf16 path answers)
+        nq2 = 1000
+        xq2 = torch.rand((nq2, d), generator=g, device=dev) - 0.5
+        xq2 = xq2 / xq2.norm(dim=1, keepdim=True)
+        _, I2 = index.search_torch(xq2, k)
+        bd = torch.full((nq2, k), float("inf"), dtype=torch.float64, device=dev)
+        bi = torch.full((nq2, k), -1, dtype=torch.int64, device=dev)
+        q64 = xq2.double()
+        sub = 250_000
+        for i in range(N // CH):
+            x = chunk(i)
+            for j in range(0, CH, sub):
+                s_ = -(q64 @ x[j:j + sub].double().T)
+                top = torch.topk(s_, k, dim=1, largest=False)
+                cd = torch.cat([bd, top.values], 1)
+                ci = torch.cat([bi, top.indices + (i * CH + j)], 1)
+                o = torch.argsort(cd, dim=1, stable=True)[:, :k]
+                bd, bi = torch.gather(cd, 1, o), torch.gather(ci, 1, o)
+                del s_
+            del x
+        recall = float((I2[:, :, None] == bi[:, None, :]).any(2).float().mean())
+        assert recall >= 0.97, recall
     del index
     torch.cuda.empty_cache()
 
