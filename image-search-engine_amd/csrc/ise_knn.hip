@@ -140,6 +140,7 @@ struct ise_index {
     std::deque<HostReq*> cq;
     int cq_leaders = 0;
     unsigned long long cq_batches = 0, cq_requests = 0;
+    unsigned long long direct_queries = 0;  // queries answered by the direct small-batch scan (under mu_)
     int num_cu = 256;
     std::mutex mu_;
 };
@@ -797,6 +798,7 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
     xs.part = w->part;  // the filter's lists are dead: [position][nblocks][kp] fits (kp <= kpass, positions <= nq)
     xs.rows_per_block = (long long)pl.tiles_per_block * 16;
     xs.arrive = reinterpret_cast<unsigned int*>(w->fl_state + 1);
+    xs.direct_n = 0;
     const size_t lds = (size_t)XQ * h->dp * 4 + (size_t)XQ * 4 * 32 * 8;
     MergeParams mp;  // the per-block lists are merged by the scan's last block
     mp.lists = w->part; mp.qt = 1; mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.metric = h->metric;
@@ -806,7 +808,7 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
         xs.kpass = k; xs.floor_keys = nullptr;
         mp.k = k; mp.stride_list = k; mp.stride_qtile = (long long)pl.nblocks * k;
         mp.D = xp.D; mp.I = xp.I; mp.keys_out = xp.keys_out; mp.out_by_pos = 0;
-        hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs, mp);
+        hipLaunchKernelGGL(exact_scan_kernel<XQ>, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs, mp);
         HIP_TRY(hipGetLastError());
         return ISE_OK;
     }
@@ -817,12 +819,65 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
         xs.kpass = kp; xs.floor_keys = off ? fb_floor : nullptr;
         mp.k = kp; mp.stride_list = kp; mp.stride_qtile = (long long)pl.nblocks * kp;
         mp.D = nullptr; mp.I = nullptr; mp.keys_out = fb_pass; mp.out_by_pos = 1;
-        hipLaunchKernelGGL(exact_scan_kernel, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs, mp);
+        hipLaunchKernelGGL(exact_scan_kernel<XQ>, dim3((unsigned)pl.nblocks), dim3(256), lds, st, xs, mp);
         const long long tot = nq * kp;
         hipLaunchKernelGGL(exact_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, xp,
                            (const u64*)fb_pass, kp, off, fb_floor);
         HIP_TRY(hipGetLastError());
     }
+    return ISE_OK;
+}
+
+// ---- small batches against float32 L2 rows: the direct-difference scan IS the search.
+// The reference searches one query per request (backend/engine.py:50-55), which in Faiss is the nq < 20
+// algorithm: fvec_L2sqr per (query, row) pair and a k-heap.  exact_scan_kernel is that algorithm (it is the
+// fallback of the filtered search, with the re-rank's own d()), so for a one-query batch it is launched on its
+// own: one kernel, no filter, no certificate, no merge kernel, and VALU work only -- the pass runs at the
+// pace of the row stream instead of at the board's power cap.  Same bits as the filtered path.
+static bool no_direct() {  // test knob, read per call: ISE_NO_DIRECT=1 sends small batches through the filter as well
+    const char* e = getenv("ISE_NO_DIRECT");
+    return e && e[0] == '1';
+}
+static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, const ScanPlan& pl, long long nq, int k,
+                           int* blocks_out) {
+    // one query only: two to four queries are VALU-bound here (380-520 us) and faster through the filter (356 us)
+    // (ISE_FORCE_EXACT asks for the filtered path's fallback to be exercised: it implies the filtered path)
+    if (!pl.exact || nq != 1 || k > KPASS_MAX || h->n <= 0 || !w->fl_state || no_direct() || force_exact()) return false;
+    // >= 64 rows per block (4 waves x XR rows x 4 steps), at most the merge's list count
+    long long blocks = std::min<long long>(MERGE_LISTS_MAX, (h->n + 63) / 64);
+    static const long long per_cu = [] { const char* e = getenv("ISE_DIRECT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return (long long)(v > 0 ? v : 2); }();
+    blocks = std::min<long long>(blocks, (long long)h->num_cu * per_cu);
+    if ((size_t)nq * blocks * k > w->part_elems) return false;  // the slot's lists are sized for the filter's plan
+    *blocks_out = (int)blocks;
+    return true;
+}
+static int direct_small_enqueue(ise_index* h, ise_index::WorkSlot* w, int blocks, const float* q_dev, long long nq, int k,
+                                uint32_t id_base, float* D_dev, long long* I_dev, u64* keys_out, hipStream_t st,
+                                TimedOut* tm) {
+    ExactScanParams xs;
+    xs.xb = (const float*)h->xb; xs.q = q_dev; xs.n = h->n; xs.d = h->d; xs.dp = h->dp;
+    xs.kpass = k; xs.id_base = id_base; xs.fl_state = w->fl_state; xs.fl_list = w->fl_list; xs.seq = 0;
+    xs.floor_keys = nullptr; xs.part = w->part;
+    xs.rows_per_block = (h->n + blocks - 1) / blocks;
+    xs.arrive = reinterpret_cast<unsigned int*>(w->fl_state + 1);
+    xs.direct_n = (int)nq;
+    MergeParams mp;
+    mp.lists = w->part; mp.qt = 1; mp.n_lists = blocks; mp.nq = (int)nq; mp.metric = h->metric;
+    mp.fl_state = w->fl_state; mp.fl_list = w->fl_list; mp.seq = 0; mp.dbg = nullptr; mp.gate = nullptr;
+    mp.k = k; mp.stride_list = k; mp.stride_qtile = (long long)blocks * k;
+    mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out; mp.out_by_pos = 0;
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
+    const int qn = 1;
+    const size_t lds = (size_t)qn * h->dp * 4 + (size_t)qn * 4 * 32 * 8;
+    // non-temporal loads: every wave instruction covers whole lines here (1 KB contiguous), where they stream
+    // faster than plain loads (336 against 359 us)
+    hipLaunchKernelGGL((exact_scan_kernel<1, true>), dim3((unsigned)blocks), dim3(256), lds, st, xs, mp);
+    HIP_TRY(hipGetLastError());
+    if (tm && tm->on) {
+        HIP_TRY(hipEventRecord(tm->e1, st));
+        HIP_TRY(hipEventRecord(tm->e2, st));
+    }
+    h->direct_queries += (unsigned long long)nq;
     return ISE_OK;
 }
 
@@ -1211,6 +1266,9 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
         return ISE_OK;
     }
 
+    int dblocks = 0;
+    if (direct_applies(h, w, pl, nq, k, &dblocks))
+        return direct_small_enqueue(h, w, dblocks, q_dev, nq, k, id_base, D_dev, I_dev, keys_out, st, tm);
     return scan_path_enqueue(h, w, pl, q_dev, nq, k, id_base, D_dev, I_dev, keys_out, st, tm, nullptr);
 }
 
@@ -1463,11 +1521,15 @@ extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq,
     return ISE_OK;
 }
 
-extern "C" int ise_index_host_stats(ise_index_t* h, uint64_t* out2) {
-    if (!h || !out2) return fail(ISE_E_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->cq_mu);
-    out2[0] = h->cq_batches;
-    out2[1] = h->cq_requests;
+extern "C" int ise_index_host_stats(ise_index_t* h, uint64_t* out3) {
+    if (!h || !out3) return fail(ISE_E_INVALID, "NULL argument");
+    {
+        std::lock_guard<std::mutex> lk(h->cq_mu);
+        out3[0] = h->cq_batches;
+        out3[1] = h->cq_requests;
+    }
+    std::lock_guard<std::mutex> lk(h->mu_);
+    out3[2] = h->direct_queries;
     return ISE_OK;
 }
 

@@ -102,10 +102,11 @@ class IndexFlat:
 
     def host_stats(self) -> dict:
         """Combining of concurrent ``search`` calls (include/ise_knn.h, ise_index_host_stats): how many
-        shared batches ran and how many calls they served."""
-        out = (ctypes.c_uint64 * 2)()
+        shared batches ran and how many calls they served; and how many queries the direct small-batch
+        scan answered (float32 L2, at most 4 queries, k <= 32)."""
+        out = (ctypes.c_uint64 * 3)()
         _n.check(_n.lib.ise_index_host_stats(self._h, out))
-        return {"combined_batches": int(out[0]), "combined_calls": int(out[1])}
+        return {"combined_batches": int(out[0]), "combined_calls": int(out[1]), "direct_queries": int(out[2])}
 
     def reserve(self, nq: int, k: int) -> None:
         """Size every internal workspace for batches of ``nq`` queries / ``k`` results now, so that the

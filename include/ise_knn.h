@@ -114,8 +114,11 @@ int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq, int k,
  * $ISE_HOST_COMBINE_MAX (default 64; 0 = never) queries of the same k, each caller getting exactly
  * the rows it would have got alone.  This is the reference's serving pattern -- one query per HTTP
  * request on a threaded Flask (backend/engine.py:55,137) -- where a scan costs the same for 1 or 16
- * queries.  ise_index_host_stats: out2[0] = batches run that way, out2[1] = calls they served. */
-int ise_index_host_stats(ise_index_t* h, uint64_t* out2);
+ * queries.  ise_index_host_stats: out3[0] = batches run that way, out3[1] = calls they served,
+ * out3[2] = queries (of any entry point) answered by the direct small-batch scan: float32 L2 batches of
+ * up to 4 queries with k <= 32 run Faiss's nq < 20 algorithm as it stands -- one direct-difference scan with
+ * a k-best list, no filter in front ($ISE_NO_DIRECT=1 sends them through the filtered path; same bits). */
+int ise_index_host_stats(ise_index_t* h, uint64_t* out3);
 int ise_index_search_device(ise_index_t* h, const float* q_dev, int64_t nq, int k,
                             float* D_dev, int64_t* I_dev, void* stream);
 

@@ -28,6 +28,17 @@ def faiss():
     return fc
 
 
+class no_direct:
+    """One-query float32 L2 batches skip the filter and run the direct-difference scan alone; with this
+    they take the filtered path like every other batch (ISE_NO_DIRECT, read per call)."""
+
+    def __enter__(self):
+        os.environ["ISE_NO_DIRECT"] = "1"
+
+    def __exit__(self, *a):
+        os.environ.pop("ISE_NO_DIRECT", None)
+
+
 class forced_exact:
     """Every certificate fails inside the block: the exact fallback scan produces the results."""
 
@@ -80,6 +91,11 @@ def test_l2_exact_on_adversarial_data(faiss, kind, nq, adds):
     D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
     n_mism = assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2, gap=ko.kth_gap(xb, xq, k, L2))
     assert n_mism == 0 or kind == "two_far_clusters"  # only float32 near-ties may differ, and only there
+    if nq == 1:  # a one-query batch is answered by the direct scan alone; the filtered path returns the same bits
+        assert index.host_stats()["direct_queries"] >= 1
+        with no_direct():
+            Df, If = index.search(xq, k)
+        assert np.array_equal(If, I) and np.array_equal(Df, D)
     st = index.exact_stats()
     assert st["reranked"] >= nq
     if kind == "two_far_clusters":
@@ -97,7 +113,8 @@ def test_certificate_holds_on_benign_data_and_forced_exact_agrees(faiss):
     for nq, k in ((1, 10), (16, 10), (40, 20), (5, 1), (7, 32), (3, 33), (4, 100)):
         xq = rng.random((nq, d), dtype=np.float32)
         before = index.exact_stats()
-        D, I = index.search(xq, k)
+        with no_direct():  # the filtered path is the subject here, for the one-query batch as well
+            D, I = index.search(xq, k)
         after = index.exact_stats()
         assert after["reranked"] - before["reranked"] == nq
         assert after["exact_scan"] == before["exact_scan"], "certificate failed on uniform data"
@@ -107,6 +124,51 @@ def test_certificate_holds_on_benign_data_and_forced_exact_agrees(faiss):
             Df, If = index.search(xq, k)
         assert index.exact_stats()["exact_scan"] - after["exact_scan"] == nq
         assert np.array_equal(If, I) and np.array_equal(Df, D)
+
+
+@pytest.mark.parametrize("n,d", [(1, 8), (63, 20), (64, 128), (5000, 100), (70_000, 512), (20_000, 2100)])
+def test_one_query_batches_run_the_direct_scan(faiss, n, d):
+    """A float32 L2 batch of ONE query with k <= 32 -- the reference's request pattern, backend/engine.py:50-55 --
+    is answered by the direct-difference scan alone (Faiss's nq < 20 algorithm as it stands: no filter, no
+    certificate): same bits as the filtered path, ids identical to the float64 oracle, through the host, the
+    device and the packed-key (shard) entry points, k from 1 to 32 and beyond the index size, odd d, duplicate
+    rows (lowest id first), rows far from the origin; larger batches and k > 32 keep the filtered path."""
+    import torch
+
+    rng = np.random.default_rng(n + d)
+    xb = (rng.random((n, d), dtype=np.float32) + np.float32(25.0 if n == 5000 else 0.0))
+    if n >= 64:
+        xb[n - 2] = xb[5]                      # duplicate rows: the lower id first
+    index = faiss.IndexFlatL2(d)
+    index.add(xb)
+    direct0 = index.host_stats()["direct_queries"]
+    asked = 0
+    for k in (1, 10, 32):
+        xq = (xb[min(5, n - 1):min(5, n - 1) + 1] + (np.float32(0.0) if k == 10 else np.float32(0.01))).astype(np.float32)
+        D, I = index.search(xq, k)
+        asked += 1
+        D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
+        assert assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2, gap=ko.kth_gap(xb, xq, k, L2)) == 0
+        if k == 10 and n >= 64:
+            assert I[0, 0] == 5 and I[0, 1] == n - 2 and D[0, 0] == 0.0 and D[0, 1] == 0.0
+        with no_direct():
+            Df, If = index.search(xq, k)
+        assert np.array_equal(If, I) and np.array_equal(Df, D), (n, d, k)
+        Dt, It = index.search_torch(torch.from_numpy(xq).cuda(), k)
+        asked += 1
+        assert np.array_equal(It.cpu().numpy(), I) and np.array_equal(Dt.cpu().numpy(), D)
+        keys = index.search_keys_torch(torch.from_numpy(xq).cuda(), k, 1000)   # shard form: ids + 1000
+        asked += 1
+        Dm, Im = faiss.merge_keys_torch(keys[None], L2)
+        assert np.array_equal(Im.cpu().numpy(), np.where(I >= 0, I + 1000, -1)) and np.array_equal(Dm.cpu().numpy(), D)
+    assert index.host_stats()["direct_queries"] - direct0 == asked
+    # not direct: two queries, k > 32 -- and the answers still agree with the one-query calls
+    two = np.concatenate([xq, xq])
+    D2, I2 = index.search(two, 32)
+    D33, I33 = index.search(xq, 33)
+    assert index.host_stats()["direct_queries"] - direct0 == asked
+    assert np.array_equal(I2[0], I[0]) and np.array_equal(I2[1], I[0]) and np.array_equal(D2[1], D[0])
+    assert np.array_equal(I33[0, :32], I[0]) and np.array_equal(D33[0, :32], D[0])
 
 
 def test_massive_duplicates_go_through_the_exact_scan(faiss):
