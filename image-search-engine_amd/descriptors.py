@@ -43,16 +43,20 @@ class SupportsDescribe(Protocol):
 class _PendingFeatures:
     """Features of a batch whose device work may still be running."""
 
-    def __init__(self, host: torch.Tensor, event):
-        self._host, self._event = host, event
+    def __init__(self, host: torch.Tensor, event, release=None):
+        self._host, self._event, self._release = host, event, release
 
     def result(self) -> torch.Tensor:
         if self._event is not None:
             self._event.synchronize()
             self._event = None
-            # out of the page-locked buffer (it is reused two batches on); a plain memcpy: a torch CPU op of
-            # this size would wake the intra-op thread pool, whose workers then spin on the decoders' cores
+            # out of the page-locked buffer (it goes back to the descriptor's pool right here); a plain memcpy:
+            # a torch CPU op of this size would wake the intra-op thread pool, whose workers then spin on the
+            # decoders' cores
             self._host = torch.from_numpy(self._host.numpy().copy())
+            release, self._release = self._release, None
+            if release is not None:
+                release()
         return self._host
 
 
@@ -286,20 +290,31 @@ class CNNDescriptor:
         f = self.extract_features_batch(images)
         if not f.is_cuda:
             return _PendingFeatures(f, None)
-        # two page-locked result buffers used alternately (allocated once: pinning memory is slow); a
-        # buffer comes round again after the batch in between has been launched, and the Describer has
-        # collected this one by then.  Events are blocking ones: a waiting host thread sleeps, it does not spin
+        # page-locked result buffers from a free list (pinning memory is slow: they are kept): a buffer belongs
+        # to the batch it was handed to until ``.result()`` has copied the features out, however many batches
+        # other threads launch in between (describe_dataset with N_JOBS > 1 shares one descriptor).  Events
+        # are blocking ones: a waiting host thread sleeps, it does not spin
         with self._stage_lock:
-            out = self._stage.setdefault("out", {"bufs": [None, None], "turn": 0})
-            i = out["turn"]
-            out["turn"] = 1 - i
-            if out["bufs"][i] is None or out["bufs"][i].numel() < f.numel():
-                out["bufs"][i] = torch.empty(max(f.numel(), 1 << 18), dtype=torch.float32, pin_memory=True)
-            host = out["bufs"][i][: f.numel()].view(f.shape)
+            free = self._stage.setdefault("out_free", [])
+            buf = None
+            for j, b in enumerate(free):
+                if b.numel() >= f.numel():
+                    buf = free.pop(j)
+                    break
+            if buf is None:
+                buf = torch.empty(max(f.numel(), 1 << 18), dtype=torch.float32, pin_memory=True)
+        host = buf[: f.numel()].view(f.shape)
         host.copy_(f, non_blocking=True)
         ev = torch.cuda.Event(blocking=True)
         ev.record(torch.cuda.current_stream(self.device))
-        return _PendingFeatures(host, ev)
+
+        def release(buf=buf):
+            with self._stage_lock:
+                pool = self._stage.setdefault("out_free", [])
+                if len(pool) < 8:
+                    pool.append(buf)
+
+        return _PendingFeatures(host, ev, release)
 
     # -- the reference's entry points
     def extract_features(self, image):
@@ -415,6 +430,7 @@ class Describer:
         # row i of the index built from that result is described_paths[i] (the reference loses this
         # when an image is skipped)
         self.described_paths: list = []
+        self._decode_lock = threading.Lock()  # the decode process pool and its slot ring: one describe() at a time
 
     def _validate_descriptors(self, descriptors):
         if not descriptors:
@@ -432,13 +448,15 @@ class Describer:
             raise Exception("Problem opening image")
         return np.ascontiguousarray(rgb[:, :, ::-1]).astype(np.uint8)
 
-    def _flush(self, pending, descriptions, final: bool = False):
-        """Describe the pending batch.  A descriptor with ``describe_batch_async`` only has its batch
+    def _flush(self, run: "_DescribeRun", final: bool = False):
+        """Describe the run's pending batch.  A descriptor with ``describe_batch_async`` only has its batch
         LAUNCHED here; the results are collected when the next batch has been launched (or at the end),
         so the device works on batch i while the host decodes, packs and uploads batch i + 1.  Lists stay
-        in input order: a batch is always collected before the next one is."""
-        if pending:
-            paths, images = zip(*pending)
+        in input order: a batch is always collected before the next one is.  Everything a call of
+        ``describe`` carries from one batch to the next lives in ``run`` -- ``describe_dataset`` calls
+        ``describe`` on ONE Describer from N_JOBS threads (backend/descriptors.py:125-129)."""
+        if run.pending:
+            paths, images, slots = zip(*run.pending)
             launched = {}
             for d_name, descriptor in self.descriptors.items():
                 if hasattr(descriptor, "describe_batch_async") and getattr(config, "DESCRIBE_ASYNC", True):
@@ -446,17 +464,18 @@ class Describer:
                         launched[d_name] = descriptor.describe_batch_async(list(images))
                     except Exception as e:  # collected below as a failed batch
                         launched[d_name] = e
-            self._collect(descriptions)
-            self._uncollected = (paths, images, launched)
-            pending.clear()
+            self._collect(run)
+            run.uncollected = (paths, images, slots, launched)
+            run.pending = []
         if final:
-            self._collect(descriptions)
+            self._collect(run)
 
-    def _collect(self, descriptions):
-        prev, self._uncollected = getattr(self, "_uncollected", None), None
+    def _collect(self, run: "_DescribeRun"):
+        prev, run.uncollected = run.uncollected, None
         if prev is None:
             return
-        paths, images, launched = prev
+        paths, images, slots, launched = prev
+        descriptions = run.descriptions
         for d_name, descriptor in self.descriptors.items():
             if d_name in launched or hasattr(descriptor, "describe_batch"):
                 try:
@@ -481,6 +500,8 @@ class Describer:
                     descriptions.paths[d_name].append(img_path)
                 except Exception as e:
                     print(f"ERROR: Problem describing image '{img_path}'\n '{e}'")
+        del images, prev  # the ring views are dead: only now may their slots be handed out again
+        run.release(slots)
 
     def _process_pool(self, procs: int):
         from concurrent.futures import ProcessPoolExecutor
@@ -538,13 +559,19 @@ class Describer:
     def describe(self, images_paths, multiprocess=False) -> dict[str, list]:
         """Decode runs ``decode_workers`` images ahead on a thread pool (PIL releases the GIL
         while decoding) so the GPU batches are not starved by JPEG decode (SURVEY.md 8f-4);
-        order and skip-on-error behaviour are those of the reference's sequential loop."""
+        order and skip-on-error behaviour are those of the reference's sequential loop.
+        Re-entrant: concurrent calls on one Describer (``describe_dataset`` with N_JOBS > 1) share
+        nothing but the decode process pool and its slot ring, which one call at a time uses."""
+        procs = max(0, int(getattr(config, "DECODE_PROCESSES", 0)))
+        if procs:  # the pool already decodes in parallel: calls that want it take turns
+            with self._decode_lock:
+                return self._describe(images_paths, procs)
+        return self._describe(images_paths, 0)
+
+    def _describe(self, images_paths, procs: int):
         from concurrent.futures import ThreadPoolExecutor
 
-        descriptions = Descriptions()
-        pending = []
         paths = np.asarray(images_paths).ravel().tolist()
-        procs = max(0, int(getattr(config, "DECODE_PROCESSES", 0)))
         workers = procs or max(1, int(getattr(config, "DECODE_WORKERS", 8)))
         window = max(workers * 4, self.batch_size)  # decoded images held ahead of the GPU: bounded
         # DECODE_PROCESSES > 0: a pool of spawned processes (the PIL thread pool tops out near 2 k images/s on
@@ -555,10 +582,11 @@ class Describer:
             from ._decode import read_image_bgr as read
             from ._decode import read_image_bgr_into
 
-            # a slot is handed out again only after its image's batch has been collected: images not yet
-            # collected number at most window (in flight) + batch_size - 1 (pending) + batch_size (launched)
+            # slots come from a free list and go back to it when their image is skipped or its batch has been
+            # collected: images holding one number at most window (in flight) + batch_size (pending, at the
+            # moment of a launch) + batch_size (launched, not yet collected)
             ring = self._slot_ring(window + 2 * self.batch_size)
-        seq = 0
+        run = _DescribeRun(ring.nslots if ring is not None else 0)
         with (_NullContext(self._process_pool(procs)) if procs else ThreadPoolExecutor(max_workers=workers)) as pool:
             inflight = collections.deque()
             it = iter(paths)
@@ -568,25 +596,45 @@ class Describer:
                     if nxt is None:
                         break
                     if ring is not None:
-                        slot = seq % ring.nslots
+                        slot = run.take_slot()
                         inflight.append((pool.submit(read_image_bgr_into, nxt, ring.path, slot, ring.slot_bytes), slot))
                     else:
                         inflight.append((pool.submit(read, nxt), -1))
-                    seq += 1
                 if not inflight:
                     break
                 fut, slot = inflight.popleft()
                 img_path, image, err = fut.result()  # input order is kept
                 if err is not None:
                     print(f"ERROR: Problem describing image '{img_path}'\n '{err}'")
+                    run.release((slot,))
                     continue
-                if isinstance(image, tuple):  # a shape: the pixels are in the ring (a view, consumed by _flush)
+                if isinstance(image, tuple):  # a shape: the pixels are in the ring (a view, dead once collected)
                     image = ring.view(slot, image)
-                pending.append((img_path, image))
-                if len(pending) >= self.batch_size:
-                    self._flush(pending, descriptions)
-        self._flush(pending, descriptions, final=True)
-        return descriptions
+                else:                         # the pixels came back themselves (larger than a slot): slot unused
+                    run.release((slot,))
+                    slot = -1
+                run.pending.append((img_path, image, slot))
+                if len(run.pending) >= self.batch_size:
+                    self._flush(run)
+        self._flush(run, final=True)
+        return run.descriptions
+
+
+class _DescribeRun:
+    """State of ONE ``Describer.describe`` call: the batch being filled, the batch launched but not yet
+    collected, the results so far, and the free slots of the decode ring."""
+
+    def __init__(self, nslots: int):
+        self.descriptions = Descriptions()
+        self.pending: list = []      # (path, image, slot)
+        self.uncollected = None      # (paths, images, slots, launched handles)
+        self.free = collections.deque(range(nslots))
+
+    def take_slot(self) -> int:
+        return self.free.popleft()   # never empty: the ring is sized for everything that can hold a slot
+
+    def release(self, slots) -> None:
+        self.free.extend(s for s in slots if s >= 0)
 
 
 def describe_dataset(describer: Describer, images_paths: np.ndarray, prediction=False) -> list:

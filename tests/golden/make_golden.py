@@ -10,7 +10,10 @@ Each .npz stores inputs (xb, xq), k, metric, expected I (int64), D (float32
 rounded from float64) and the smallest float64 gap between consecutive ranks
 1..k+1 per query, so a test can tell a real mismatch from a float32 near-tie.
 
-Run:  python tests/golden/make_golden.py
+Run:  python tests/golden/make_golden.py            (re)write the fixtures
+      python tests/golden/make_golden.py --check    regenerate every fixture into a scratch directory and
+                                                    compare it, array by array and bit for bit, with the
+                                                    committed file (also a CPU test: tests/test_oracle.py)
 """
 import os
 import sys
@@ -21,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import knn_oracle as ko  # noqa: E402
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE  # where emit() writes; --check points it at a scratch directory
 L2, IP = ko.METRIC_L2, ko.METRIC_INNER_PRODUCT
 
 
@@ -138,7 +142,56 @@ def main_seeded():
     emit_seeded("seeded_assign_l2_n2048_c256_d128", "assign", 22, 256, 128, 2048, 1, L2)
 
 
+def check(scratch=None, verbose=True):
+    """Regenerate everything into ``scratch`` and compare with the committed fixtures.  Returns the list of
+    (file, problem) differences (empty = every committed .npz is reproduced bit for bit and none is missing
+    or left over)."""
+    import glob
+    import tempfile
+
+    global OUT
+    saved = OUT
+    problems = []
+    with tempfile.TemporaryDirectory(dir=scratch) as tmp:
+        OUT = tmp
+        try:
+            if verbose:
+                main()
+                main_seeded()
+            else:
+                import contextlib
+                import io
+
+                with contextlib.redirect_stdout(io.StringIO()):
+                    main()
+                    main_seeded()
+        finally:
+            OUT = saved
+        new = {os.path.basename(f) for f in glob.glob(os.path.join(tmp, "*.npz"))}
+        old = {os.path.basename(f) for f in glob.glob(os.path.join(HERE, "*.npz"))}
+        for name in sorted(old - new):
+            problems.append((name, "committed but not generated"))
+        for name in sorted(new - old):
+            problems.append((name, "generated but not committed"))
+        for name in sorted(new & old):
+            a, b = np.load(os.path.join(tmp, name)), np.load(os.path.join(HERE, name))
+            if sorted(a.files) != sorted(b.files):
+                problems.append((name, f"keys {sorted(a.files)} != {sorted(b.files)}"))
+                continue
+            for key in a.files:
+                x, y = a[key], b[key]
+                if x.dtype != y.dtype or x.shape != y.shape or x.tobytes() != y.tobytes():
+                    problems.append((name, f"array '{key}' differs"))
+    return problems
+
+
 if __name__ == "__main__":
+    if "--check" in sys.argv:
+        bad = check()
+        for name, what in bad:
+            print(f"MISMATCH {name}: {what}")
+        print("golden fixtures reproduced bit for bit" if not bad else f"{len(bad)} differences")
+        raise SystemExit(1 if bad else 0)
     if "--seeded" in sys.argv:   # only the seeded fixtures (the stored ones above stay byte-identical)
         main_seeded()
     else:

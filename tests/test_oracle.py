@@ -137,3 +137,85 @@ def test_lloyd_reference_against_sklearn():
     assert all(b >= a - 1e-9 for a, b in zip(objs, objs[1:]))
     with pytest.raises(ValueError, match="empty cluster"):
         ko.lloyd_reference(x, np.concatenate([c0[:-1], c0[-1:] * 0 + 1e6]), 2)
+
+
+# ---- standing independence checks.  The reference holds no fixture and Faiss is not
+# importable here, so the oracle stays "parity unpinned"; what CAN be had in this container is agreement
+# with two implementations that share no code with oracle/: sklearn's brute-force NearestNeighbors
+# (sqeuclidean) and torch's float64 cdist / matmul + topk.  They run on every golden and on a fresh random
+# draw per test run (the seed is printed on failure), against both oracles.
+def _independent_topk(xb, xq, k, metric):
+    """(ids by torch float64, ids by sklearn float64 or None, float64 scores of the torch ids)"""
+    import torch
+
+    tb, tq = torch.from_numpy(xb).double(), torch.from_numpy(xq).double()
+    if metric == L2:
+        from sklearn.neighbors import NearestNeighbors
+
+        S = torch.cdist(tq, tb, compute_mode="donot_use_mm_for_euclid_dist") ** 2
+        v, i = torch.topk(S, k, dim=1, largest=False)
+        nn = NearestNeighbors(n_neighbors=k, algorithm="brute", metric="sqeuclidean").fit(xb.astype(np.float64))
+        _, si = nn.kneighbors(xq.astype(np.float64))
+        return i.numpy(), si, v.numpy()
+    S = tq @ tb.T
+    v, i = torch.topk(S, k, dim=1, largest=True)
+    return i.numpy(), None, v.numpy()
+
+
+def _assert_oracles_agree_with_independent(xb, xq, k, metric, tag):
+    if xb.shape[0] < k:  # padding cases: the cross-checkers have no notion of -1 / FLT_MAX padding
+        return
+    gap = ko.kth_gap(xb, xq, k, metric)
+    clear = gap > 1e-9  # exact float64 ties (duplicate rows) may be ordered differently by the cross-checkers
+    ti, si, tv = _independent_topk(xb, xq, k, metric)
+    D, I = ko.knn_exact(xb, xq, k, metric)
+    assert np.array_equal(ti[clear], I[clear]), f"{tag}: torch float64 disagrees with knn_exact"
+    if si is not None:
+        assert np.array_equal(si[clear], I[clear]), f"{tag}: sklearn brute force disagrees with knn_exact"
+    np.testing.assert_allclose(tv[clear], D[clear], rtol=1e-6, atol=1e-6, err_msg=tag)
+    # on tied queries the SET of distances must still agree
+    np.testing.assert_allclose(np.sort(tv, axis=1), np.sort(D.astype(np.float64), axis=1), rtol=1e-6, atol=1e-6,
+                               err_msg=tag)
+    # the float32 C restatement: ids equal where float32 resolves the ranks, near-ties otherwise
+    for nthreads in (0, 3):
+        Dc, Ic, _ = fo.knn_flat(xb, xq, k, metric, nthreads)
+        assert_knn_matches(Dc, Ic, tv.astype(np.float32), ti.astype(np.int64), xb, xq, metric, gap=gap)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
+def test_oracles_against_sklearn_and_torch_on_goldens(path):
+    pytest.importorskip("sklearn")
+    z = load_fixture(path)
+    _assert_oracles_agree_with_independent(z["xb"], z["xq"], int(z["k"]), int(z["metric"]), os.path.basename(path))
+
+
+def test_oracles_against_sklearn_and_torch_on_a_fresh_draw():
+    pytest.importorskip("sklearn")
+    seed = int.from_bytes(os.urandom(4), "little")
+    rng = np.random.default_rng(seed)
+    for case in range(6):
+        n, d = int(rng.integers(50, 3000)), int(rng.integers(1, 300))
+        nq, k = int(rng.integers(1, 40)), int(rng.integers(1, min(n, 40) + 1))
+        kind = case % 3
+        if kind == 0:
+            xb, xq = rng.random((n, d), dtype=np.float32), rng.random((nq, d), dtype=np.float32)
+        elif kind == 1:  # offset + spread: the CNN-embedding shape of the data (large common component)
+            xb = (50.0 + rng.standard_normal((n, d))).astype(np.float32)
+            xq = (50.0 + rng.standard_normal((nq, d))).astype(np.float32)
+        else:            # unit rows (the "cosine" index of backend/utils.py:300-303)
+            xb = ko.normalize_rows(rng.standard_normal((n, d)).astype(np.float32))
+            xq = ko.normalize_rows(rng.standard_normal((nq, d)).astype(np.float32))
+        for metric in (L2, IP):
+            _assert_oracles_agree_with_independent(xb, xq, k, metric, f"seed {seed} case {case} metric {metric} "
+                                                   f"n={n} d={d} nq={nq} k={k}")
+
+
+def test_make_golden_check_reproduces_every_committed_fixture(golden_dir):
+    """tests/golden/make_golden.py --check: every committed .npz comes out of the generator bit for bit
+    (array by array), none missing, none left over -- the fixtures are what the script says they are."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    assert mg.check(verbose=False) == []

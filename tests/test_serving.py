@@ -281,6 +281,82 @@ def test_process_pool_decoder_gives_the_same_descriptions(tmp_path, monkeypatch)
         assert np.array_equal(outs[name][0], outs["threads"][0]), name
 
 
+def test_runs_of_broken_files_never_hand_out_a_live_ring_slot(tmp_path, monkeypatch):
+    """ring slots come from a free list and go back to it only when their image is skipped or its
+    batch has been collected.  Runs of broken files (3 and 8 in a row) in front of a slow describe-only
+    descriptor -- which reads the ring views one flush late -- used to let a decode worker overwrite pixels
+    that were still pending (2 of 114 rows wrong)."""
+    import time
+
+    from image_search_engine_amd import descriptors as ds
+
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib")
+    rng = np.random.default_rng(11)
+    paths = _write_images(tmp_path / "data", 120, rng, size=20)
+    for i in (9, 10, 11, 40, 41, 42, 43, 44, 45, 46, 47, 90):
+        paths[i].write_bytes(b"broken")
+    arr = np.array(paths).reshape(-1, 1)
+
+    class _Slow(_MeanColourDescriptor):
+        def describe(self, image):
+            time.sleep(0.002)
+            return super().describe(image)
+
+    outs = {}
+    for name, procs in (("threads", 0), ("ring", 3)):
+        monkeypatch.setattr(Config, "DECODE_PROCESSES", procs)
+        describer = ds.Describer({"conv_features": _Slow()}, batch_size=5)
+        out = ds.describe_dataset(describer, arr)
+        outs[name] = (np.concatenate([np.asarray(o) for o in out]), list(describer.described_paths))
+        describer.close()
+    assert len(outs["threads"][1]) == 108
+    assert outs["ring"][1] == outs["threads"][1]
+    assert np.array_equal(outs["ring"][0], outs["threads"][0])
+
+
+@pytest.mark.parametrize("procs", [0, 2])
+def test_describe_dataset_with_several_jobs_keeps_every_row_in_order(tmp_path, monkeypatch, procs):
+    """describe_dataset runs describer.describe on ONE Describer from N_JOBS threads
+    (backend/descriptors.py:125-129); the batch a call has launched but not collected is that call's own
+    (it used to sit on the Describer, where the threads stole each other's: 190 of 200 rows came back)."""
+    import time
+
+    from image_search_engine_amd import descriptors as ds
+
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", tmp_path / "absent.joblib")
+    monkeypatch.setattr(Config, "N_JOBS", 4)
+    monkeypatch.setattr(Config, "DECODE_PROCESSES", procs)
+    rng = np.random.default_rng(12)
+    paths = _write_images(tmp_path / "data", 200, rng, size=12)
+    paths[17].write_bytes(b"broken")
+
+    class _AsyncSlow(_MeanColourDescriptor):
+        """describe_batch_async whose result is ready only a little later, like a device batch"""
+
+        def describe_batch_async(self, images):
+            import torch
+
+            feats = torch.stack([_MeanColourDescriptor.describe(self, im) for im in images])
+
+            class _H:
+                def result(self_h):
+                    time.sleep(0.002)
+                    return feats
+
+            return _H()
+
+    describer = ds.Describer({"conv_features": _AsyncSlow()}, batch_size=7)
+    out = ds.describe_dataset(describer, np.array(paths).reshape(-1, 1))
+    describer.close()
+    kept = [p for i, p in enumerate(paths) if i != 17]
+    assert len(out) == 199 and describer.described_paths == kept
+    from PIL import Image
+
+    want = np.stack([np.tile(np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1].reshape(-1, 3).mean(0), 4)
+                     for p in kept]).astype(np.float32)
+    assert np.array_equal(np.concatenate([np.asarray(o) for o in out]), want)
+
+
 def test_describer_collects_async_batches_in_order(tmp_path, monkeypatch):
     """A descriptor with describe_batch_async has batch i + 1 launched before batch i is collected; the
     lists still come out in input order, a batch whose launch or result fails is redone image by image,
