@@ -58,6 +58,9 @@ PROTOTYPES = [
     ("ise_normalize_rows_device", _int, [_vp, _i64, _int, _int, _vp]),
     ("ise_normalize_rows_host", _int, [_vp, _i64, _int, _int]),
     ("ise_bovw_histogram_device", _int, [_vp, _vp, _i64, _int, _vp, _int, _vp]),
+    ("ise_index_short_stats", _int, [_vp, _vp]),
+    ("ise_refresh_env_knobs", _int, []),
+    ("ise_comm_precheck", _int, [_int]),
     ("ise_comm_unique_id", _int, [_vp]),
     ("ise_comm_create", _int, [ctypes.POINTER(_vp), _vp, _int, _int, _int]),
     ("ise_comm_allgather_keys", _int, [_vp, _vp, _vp, _i64, _vp]),

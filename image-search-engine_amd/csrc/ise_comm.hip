@@ -66,6 +66,23 @@ struct ise_comm {
     int world = 0, rank = 0, device = 0;
 };
 
+extern "C" int ise_comm_precheck(int device) {
+    RcclApi* a = rccl();
+    if (!a->err.empty()) return ise_fail_(ISE_E_NODEVICE, a->err);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return ise_fail_(ISE_E_NODEVICE, "device out of range (the collective needs a GPU)");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return ise_fail_(ISE_E_HIP, "hipSetDevice failed");
+    void* probe = nullptr;  // the device really is usable from this process
+    const hipError_t e = hipMalloc(&probe, 256);
+    if (e == hipSuccess) (void)hipFree(probe);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return ise_fail_(ISE_E_HIP, std::string("device probe failed: ") + hipGetErrorString(e));
+    return ISE_OK;
+}
+
 extern "C" int ise_comm_unique_id(void* id128) {
     if (!id128) return ise_fail_(ISE_E_INVALID, "id128 is NULL");
     RcclApi* a = rccl();

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <condition_variable>
 #include <cstdint>
@@ -72,6 +73,23 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set once per (kernel, device),
+// race-free (one static LdsAttrOnce per launcher; the launch that follows is ordered behind the set by the mutex)
+struct LdsAttrOnce {
+    std::atomic<unsigned long long> done{0};  // bit i: set on device i (< 64 devices per process)
+    std::mutex mu;
+    void ensure(const void* kernel, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        const unsigned long long bit = 1ull << dev;
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 // dev builds (-DISE_ABLATE): block 0 / lane 0 stamps the 100 MHz real-time clock into a debug buffer
 #ifdef ISE_ABLATE

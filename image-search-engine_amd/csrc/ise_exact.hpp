@@ -227,7 +227,7 @@ __device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsign
 }
 
 // standalone form: candidates [nq][kc] in HBM (the multi-pass path, kc > 32)
-__global__ __launch_bounds__(256) void rerank_kernel(const ExactParams p, const u64* keys_in) {
+static __global__ __launch_bounds__(256) void rerank_kernel(const ExactParams p, const u64* keys_in) {
     extern __shared__ __align__(16) unsigned char smem_rr[];
     rerank_stage_query<256>(p, (int)blockIdx.x, smem_rr);
     rerank_block<256>(p, (int)blockIdx.x, smem_rr, keys_in);

@@ -37,6 +37,7 @@
 #include "ise_gemm_scan.hpp"
 #include "ise_gemm_bf16.hpp"
 #include "ise_rows.hpp"
+#include "ise_short_scan.hpp"
 
 // ---------------------------------------------------------------- host side
 static thread_local std::string g_err;
@@ -105,6 +106,8 @@ struct ise_index {
         int* fl_list = nullptr;   // [fl_elems] the listed queries
         size_t fl_elems = 0;
         uint32_t fl_seq = 0;      // bumped per rerank launch, never reset while fl_state lives
+        unsigned int* arrive = nullptr;  // short-index kernel: monotonic count of blocks that have written their lists
+        unsigned int arrive_count = 0;   // its value once every launch enqueued so far has run
         hipEvent_t done = nullptr;
         bool used = false;
         hipStream_t last_stream = nullptr;  // valid when used
@@ -141,6 +144,7 @@ struct ise_index {
     int cq_leaders = 0;
     unsigned long long cq_batches = 0, cq_requests = 0;
     unsigned long long direct_queries = 0;  // queries answered by the direct small-batch scan (under mu_)
+    unsigned long long short_batches = 0;   // batches answered by one launch of the short-index kernel (under mu_)
     int num_cu = 256;
     std::mutex mu_;
 };
@@ -251,6 +255,7 @@ static void free_all(ise_index* h) {
         if (w.gemm) (void)hipFree(w.gemm);
         if (w.fl_state) (void)hipFree(w.fl_state);
         if (w.fl_list) (void)hipFree(w.fl_list);
+        if (w.arrive) (void)hipFree(w.arrive);
         if (w.done) (void)hipEventDestroy(w.done);
         w = ise_index::WorkSlot();
     }
@@ -537,6 +542,13 @@ static void launch_scan(const ise_index* h, int ch, int waves, int T, dim3 grid,
     else ise_launch_scan_f32_plain(ch, waves, T, grid, lds, st, sp);
 }
 
+static void launch_short(const ise_index* h, int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp,
+                         const ShortTailParams& tp) {
+    if (h->storage == ISE_STORE_BF16) ise_launch_short_bf16(ch, grid, lds, st, sp, tp);
+    else if (uses_shift(h)) ise_launch_short_f32_shift(ch, grid, lds, st, sp, tp);
+    else ise_launch_short_f32_plain(ch, grid, lds, st, sp, tp);
+}
+
 struct ScanPlan {
     int nblocks, tiles_total, tiles_per_block, nqt, ch, kpass, kb, waves, T;
     size_t lds;
@@ -544,6 +556,7 @@ struct ScanPlan {
     int kc;      // keys per query the scan + merge stage selects: k, or k + extra candidates when exact
     bool gemm;   // the batch takes the large-batch path (ise_gemm_scan.hpp): the slot also holds its buffers
     size_t gemm_bytes;
+    bool short_;  // the batch runs as ONE launch of the short-index kernel (ise_short_scan.hpp)
 };
 
 // candidates kept beyond k on the exact path: enough that the certificate holds on data whose
@@ -558,10 +571,36 @@ static int exact_extra(int k) {
 // relative width of the scan's lower bound: every rounding between the stored floats and the keyed
 // value, in units of u = 2^-24 times (|x-mu|^2 + |y-mu|^2) (derivation: DESIGN.md section 4.1)
 static float exact_beta(const ise_index* h) { return (0.5625f * h->dp + 256.f) * 5.9604645e-8f * 1.02f; }
-static bool force_exact() {  // test knob, read per call: ISE_FORCE_EXACT=1 fails every certificate (exercises the exact scan)
-    const char* e = getenv("ISE_FORCE_EXACT");
-    return e && e[0] == '1';
+// Test / rehearsal knobs that may change while the process runs: read from the environment when the library
+// is first used and again whenever ise_refresh_env_knobs() is called (the tests call it after changing the
+// environment) -- never inside a search, where another thread's setenv would race with getenv.
+struct EnvKnobs {
+    std::atomic<int> force_exact{0};    // ISE_FORCE_EXACT=1: fail every certificate (exercises the exact scan)
+    std::atomic<int> no_direct{0};      // ISE_NO_DIRECT=1: one-query batches take the filtered path as well
+    std::atomic<int> no_short{0};       // ISE_NO_SHORT=1: short indexes take the streaming kernel + merge launches
+    std::atomic<int> short_tpb_max{0};  // ISE_SHORT_TPB_MAX: most row tiles per block the short-index kernel takes
+    std::atomic<int> direct_min_tiles{0};  // ISE_DIRECT_MIN_TILES: shortest index (16-row tiles) the direct one-query scan takes
+    void refresh() {
+        auto flag = [](const char* name) { const char* e = getenv(name); return (e && e[0] == '1') ? 1 : 0; };
+        auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+        force_exact.store(flag("ISE_FORCE_EXACT"));
+        no_direct.store(flag("ISE_NO_DIRECT"));
+        no_short.store(flag("ISE_NO_SHORT"));
+        short_tpb_max.store(num("ISE_SHORT_TPB_MAX"));
+        direct_min_tiles.store(num("ISE_DIRECT_MIN_TILES"));
+    }
+};
+static EnvKnobs& knobs() {
+    static EnvKnobs k;
+    static std::once_flag once;
+    std::call_once(once, [] { k.refresh(); });
+    return k;
 }
+extern "C" int ise_refresh_env_knobs(void) {
+    knobs().refresh();
+    return ISE_OK;
+}
+static bool force_exact() { return knobs().force_exact.load(std::memory_order_relaxed) != 0; }
 
 static bool xchg_enabled() {  // dev knob: ISE_NO_XCHG=1 switches the threshold exchange off
     static const bool on = [] { const char* e = getenv("ISE_NO_XCHG"); return !(e && e[0] == '1'); }();
@@ -570,7 +609,7 @@ static bool xchg_enabled() {  // dev knob: ISE_NO_XCHG=1 switches the threshold 
 
 // pick (query tiles per pass T, waves per block) for nq queries: the largest T <= 3
 // that the batch can use and whose LDS image fits, preferring 8 waves
-static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
+static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool allow_short = true) {
     pl->exact = uses_shift(h);
     pl->kc = pl->exact ? k + exact_extra(k) : k;
     pl->kpass = pl->kc < KPASS_MAX ? pl->kc : KPASS_MAX;
@@ -648,6 +687,31 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl) {
     pl->nqt = (int)((nq + 16 * pl->T - 1) / (16 * pl->T));
     pl->gemm = false;
     pl->gemm_bytes = 0;
+    pl->short_ = false;
+    // Short indexes, one query tile, one pass: the whole batch is ONE launch of short_scan_kernel (scores dumped
+    // to LDS, one selection per block, merge + re-rank by the last blocks to arrive).  Two 8-wave blocks per CU
+    // when their LDS images fit side by side, else one; a block's rows must fit the selection (SHORT_TPB_MAX tiles).
+    if (allow_short && nq <= 16 && pl->kc <= pl->kpass && h->n > 0 && !knobs().no_short.load(std::memory_order_relaxed)) {
+        int tpb_max = knobs().short_tpb_max.load(std::memory_order_relaxed);
+        if (tpb_max <= 0 || tpb_max > SHORT_TPB_MAX) tpb_max = SHORT_TPB_MAX;
+        const int S = qs_stride_for(h);
+        for (int bpc = 2; bpc >= 1 && !pl->short_; bpc--) {
+            int nbs = std::min(h->num_cu * bpc, (pl->tiles_total + SHORT_W - 1) / SHORT_W);
+            nbs = std::max(1, std::min(nbs, MERGE_LISTS_MAX));
+            const int tpb = (pl->tiles_total + nbs - 1) / nbs;
+            const size_t lds = short_lds_layout(S, tpb, h->dp, pl->kc) + 64 /* the kernel's static words */;
+            if (tpb <= tpb_max && lds <= (size_t)LDS_LIMIT / bpc) {
+                pl->short_ = true;
+                pl->nblocks = nbs;
+                pl->tiles_per_block = tpb;
+                pl->lds = lds - 64;
+                pl->waves = SHORT_W;
+                pl->T = 1;
+                pl->nqt = 1;
+                pl->ch = std::min(chunk_steps(h), 4);
+            }
+        }
+    }
     return ISE_OK;
 }
 
@@ -699,6 +763,12 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
             w->gemm_bytes = needg;
             *changed = true;
         }
+    }
+    if (pl.short_ && !w->arrive) {
+        HIP_TRY(hipMalloc(&w->arrive, 256));
+        HIP_TRY(hipMemset(w->arrive, 0, 256));
+        w->arrive_count = 0;
+        *changed = true;
     }
     if (pl.exact) {
         if (!w->fl_state) {
@@ -834,15 +904,16 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
 // fallback of the filtered search, with the re-rank's own d()), so for a one-query batch it is launched on its
 // own: one kernel, no filter, no certificate, no merge kernel, and VALU work only -- the pass runs at the
 // pace of the row stream instead of at the board's power cap.  Same bits as the filtered path.
-static bool no_direct() {  // test knob, read per call: ISE_NO_DIRECT=1 sends small batches through the filter as well
-    const char* e = getenv("ISE_NO_DIRECT");
-    return e && e[0] == '1';
-}
+static bool no_direct() { return knobs().no_direct.load(std::memory_order_relaxed) != 0; }
 static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, const ScanPlan& pl, long long nq, int k,
                            int* blocks_out) {
     // one query only: two to four queries are VALU-bound here (380-520 us) and faster through the filter (356 us)
     // (ISE_FORCE_EXACT asks for the filtered path's fallback to be exercised: it implies the filtered path)
     if (!pl.exact || nq != 1 || k > KPASS_MAX || h->n <= 0 || !w->fl_state || no_direct() || force_exact()) return false;
+    // short indexes: the one-launch filtered search (ise_short_scan.hpp) is faster than this scan's serial tail
+    // (100k x 512: 60 us direct); $ISE_DIRECT_MIN_TILES moves the crossover for experiments
+    const int min_tiles = knobs().direct_min_tiles.load(std::memory_order_relaxed);
+    if (pl.short_ && (min_tiles <= 0 || pl.tiles_total < min_tiles)) return false;
     // >= 64 rows per block (4 waves x XR rows x 4 steps), at most the merge's list count
     long long blocks = std::min<long long>(MERGE_LISTS_MAX, (h->n + 63) / 64);
     static const long long per_cu = [] { const char* e = getenv("ISE_DIRECT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return (long long)(v > 0 ? v : 2); }();
@@ -930,12 +1001,8 @@ static int plan_for_batch(const ise_index* h, long long nq, int k, ScanPlan* pl)
 
 template <int NS, bool DUMP>
 static void launch_gemm_one(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_scan_kernel<NS, DUMP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-        attr_done = true;
-    }
+    static LdsAttrOnce attr;
+    attr.ensure(reinterpret_cast<const void*>(&gemm_scan_kernel<NS, DUMP>), LDS_LIMIT);
     hipLaunchKernelGGL((gemm_scan_kernel<NS, DUMP>), dim3(grid), dim3(512), lds, st, gp);
 }
 template <bool DUMP>
@@ -1068,6 +1135,32 @@ static int scan_path_enqueue(ise_index* h, ise_index::WorkSlot* w, const ScanPla
     xp.force_fail = force_exact() ? 1 : 0;
     xp.tau_bound = nullptr;
 
+    if (pl.short_) {  // one launch: scan + per-block selection + merge (+ exact re-rank) by the last blocks to arrive
+        if (gate) return fail(ISE_E_INVALID, "internal: a gated rerun was planned for the short-index kernel");
+        ShortTailParams tp;
+        tp.mp = mp;
+        tp.mp.qt = 16; tp.mp.stride_list = 16ll * pl.kpass; tp.mp.stride_qtile = (long long)pl.nblocks * 16 * pl.kpass;
+        tp.mp.dbg = nullptr;
+        tp.xp = xp;
+        tp.arrive = w->arrive;
+        tp.arrive_base = w->arrive_count;
+        tp.gave_up = h->stats_dev + 2;
+        w->arrive_count += (unsigned int)pl.nblocks;
+        h->short_batches++;
+        if (pl.exact) {
+            if ((rc = next_fl_seq(w, st, &tp.xp.seq))) return rc;
+            tp.mp.D = nullptr; tp.mp.I = nullptr; tp.mp.keys_out = nullptr;
+        } else {
+            tp.mp.D = D_dev; tp.mp.I = I_dev; tp.mp.keys_out = keys_out;
+        }
+        if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
+        launch_short(h, pl.ch, pl.nblocks, pl.lds, st, sp, tp);
+        HIP_TRY(hipGetLastError());
+        if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
+        if (pl.exact && (rc = enqueue_exact_fallback(h, w, pl, tp.xp, nq, st))) return rc;
+        if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e2, st));
+        return ISE_OK;
+    }
     const dim3 grid((unsigned)pl.nblocks, (unsigned)pl.nqt);
     if (pl.kc <= pl.kpass) {  // one scan pass selects everything the merge stage needs
         if ((rc = next_xchg_seq(w, st, &sp.xchg_seq))) return rc;
@@ -1131,12 +1224,8 @@ static int scan_path_enqueue(ise_index* h, ise_index::WorkSlot* w, const ScanPla
 
 template <int NS, bool DUMP, bool L2>
 static void launch_gemm_bf16_metric(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_scan_bf16_kernel<NS, DUMP, L2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-        attr_done = true;
-    }
+    static LdsAttrOnce attr;
+    attr.ensure(reinterpret_cast<const void*>(&gemm_scan_bf16_kernel<NS, DUMP, L2>), LDS_LIMIT);
     hipLaunchKernelGGL((gemm_scan_bf16_kernel<NS, DUMP, L2>), dim3(grid), dim3(512), lds, st, gp);
 }
 template <int NS, bool DUMP>
@@ -1219,7 +1308,7 @@ static int search_large_chunk_bf16(ise_index* h, ise_index::WorkSlot* w, const f
     HIP_TRY(hipGetLastError());
     // incomplete candidates anywhere in the chunk: the streaming passes answer the whole chunk instead
     ScanPlan pl;
-    rc = make_plan(h, nq, k, &pl);
+    rc = make_plan(h, nq, k, &pl, /*allow_short=*/false);  // a gated rerun: the streaming kernels carry the gate
     if (rc) return rc;
     rc = scan_path_enqueue(h, w, pl, q_dev, nq, k, id_base, D_dev, I_dev, keys_out, st, nullptr, rerun);
     if (rc) return rc;
@@ -1521,6 +1610,18 @@ extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq,
     return ISE_OK;
 }
 
+extern "C" int ise_index_short_stats(ise_index_t* h, uint64_t* out2) {
+    if (!h || !out2) return fail(ISE_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu_);
+    DeviceGuard gd(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long gave_up = 0;
+    HIP_TRY(hipMemcpy(&gave_up, h->stats_dev + 2, sizeof(gave_up), hipMemcpyDeviceToHost));
+    out2[0] = h->short_batches;
+    out2[1] = gave_up;
+    return ISE_OK;
+}
+
 extern "C" int ise_index_host_stats(ise_index_t* h, uint64_t* out3) {
     if (!h || !out3) return fail(ISE_E_INVALID, "NULL argument");
     {
@@ -1583,12 +1684,8 @@ static size_t assign_lds_bytes(const ise_index* h) {
 
 template <int NS, int XT>
 static void launch_assign(int grid, size_t lds, hipStream_t st, const AssignParams& ap) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_kernel<NS, XT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-        attr_done = true;
-    }
+    static LdsAttrOnce attr;
+    attr.ensure(reinterpret_cast<const void*>(&assign_kernel<NS, XT>), LDS_LIMIT);
     hipLaunchKernelGGL((assign_kernel<NS, XT>), dim3(grid), dim3(512), lds, st, ap);
 }
 

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(const MergeParams 
 
 // Up to 64 lists (the all-gathered per-rank lists of the multi-GPU path): one wave per query,
 // one list per lane, no LDS and no barriers.
-__global__ __launch_bounds__(256) void merge_small_kernel(const MergeParams p) {
+static __global__ __launch_bounds__(256) void merge_small_kernel(const MergeParams p) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= p.nq) return;

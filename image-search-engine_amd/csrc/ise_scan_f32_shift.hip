@@ -1,6 +1,11 @@
 // scan_kernel family: float32 rows, centred L2 (SHIFT).  Own translation unit so the families compile in parallel.
 #include "ise_scan_launch.hpp"
+#include "ise_short_scan.hpp"
 
 void ise_launch_scan_f32_shift(int ch, int waves, int T, dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
     launch_scan_v<false, true>(ch, waves, T, grid, lds, st, sp);
+}
+
+void ise_launch_short_f32_shift(int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortTailParams& tp) {
+    launch_short_v<false, true, true>(ch, grid, lds, st, sp, tp);
 }

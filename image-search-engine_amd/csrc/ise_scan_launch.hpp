@@ -5,12 +5,8 @@
 
 template <int CH, int W, int T, bool BF16, bool SHIFT>
 static void launch_one(dim3 grid, size_t lds, hipStream_t st, const ScanParams& sp) {
-    static bool attr_done = false;  // benign race: the attribute is idempotent
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<CH, W, T, BF16, SHIFT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-        attr_done = true;
-    }
+    static LdsAttrOnce attr;
+    attr.ensure(reinterpret_cast<const void*>(&scan_kernel<CH, W, T, BF16, SHIFT>), LDS_LIMIT);
     hipLaunchKernelGGL((scan_kernel<CH, W, T, BF16, SHIFT>), grid, dim3(W * 64), lds, st, sp);
 }
 template <int W, int T, bool BF16, bool SHIFT>

@@ -29,6 +29,41 @@ def paths_file_for(index_path):
     return p.with_name(p.name + ".paths.json")
 
 
+def file_crc32(path) -> int:
+    import zlib
+
+    crc = 0
+    with open(str(path), "rb") as f:
+        while True:
+            blk = f.read(1 << 22)
+            if not blk:
+                return crc
+            crc = zlib.crc32(blk, crc)
+
+
+def read_paths_file(index_path, ntotal):
+    """The paths list written beside ``index_path``, or None when there is none or it belongs to another
+    build of the index (row count or checksum differ; a bare list -- the first format -- is only checked
+    for its length)."""
+    from pathlib import Path
+
+    pf = paths_file_for(index_path)
+    if not pf.exists():
+        return None
+    with open(pf) as f:
+        rec = json.load(f)
+    if isinstance(rec, list):
+        rec = {"paths": rec}
+    paths = rec.get("paths", [])
+    if len(paths) != ntotal or rec.get("ntotal", ntotal) != ntotal:
+        print(f"WARNING: {pf} lists {len(paths)} paths for an index of {ntotal} rows: ignored")
+        return None
+    if "index_crc32" in rec and rec["index_crc32"] != file_crc32(index_path):
+        print(f"WARNING: {pf} was written for another build of {index_path} (checksum differs): ignored")
+        return None
+    return [Path(p) for p in paths]
+
+
 def load(index_path=None, paths=None, desc=None):
     """Bind the module globals (backend/engine.py:110-117 for METHOD=DNN).
 
@@ -40,13 +75,11 @@ def load(index_path=None, paths=None, desc=None):
     global index, images_paths, descriptor
     index_path = index_path or config.DNN_INDEX_PATH
     index = faiss.read_index(str(index_path))
+    listed = read_paths_file(index_path, index.ntotal) if paths is None else None
     if paths is not None:
         images_paths = paths
-    elif paths_file_for(index_path).exists():
-        from pathlib import Path
-
-        with open(paths_file_for(index_path)) as f:
-            images_paths = [Path(p) for p in json.load(f)]
+    elif listed is not None:
+        images_paths = listed
     else:
         images_paths = get_images_paths()
     if len(images_paths) != index.ntotal:

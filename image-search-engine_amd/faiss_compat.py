@@ -108,6 +108,13 @@ class IndexFlat:
         _n.check(_n.lib.ise_index_host_stats(self._h, out))
         return {"combined_batches": int(out[0]), "combined_calls": int(out[1]), "direct_queries": int(out[2])}
 
+    def short_stats(self) -> dict:
+        """The one-launch search of short indexes (include/ise_knn.h, ise_index_short_stats): batches it
+        answered, tail blocks that stopped waiting for the grid (expected 0)."""
+        out = (ctypes.c_uint64 * 2)()
+        _n.check(_n.lib.ise_index_short_stats(self._h, out))
+        return {"short_batches": int(out[0]), "gave_up": int(out[1])}
+
     def reserve(self, nq: int, k: int) -> None:
         """Size every internal workspace for batches of ``nq`` queries / ``k`` results now, so that the
         first search of that shape allocates nothing (serving loops, bench.py)."""

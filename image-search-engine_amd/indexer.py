@@ -32,14 +32,20 @@ def main():
     faiss.write_index(index, str(config.DNN_INDEX_PATH))
     # row id -> image path of the rows actually indexed (skipped images leave no row): the engine
     # reads this instead of re-globbing the data folder (fixes SURVEY.md quirk 5.9-4)
-    from .engine import paths_file_for
+    from .engine import file_crc32, paths_file_for
 
     described = [str(p) for p in np.asarray(describer.described_paths, dtype=object).ravel().tolist()]
+    paths_file = paths_file_for(config.DNN_INDEX_PATH)
     if len(described) == index.ntotal:
-        with open(paths_file_for(config.DNN_INDEX_PATH), "w") as f:
-            json.dump(described, f)
+        # the list names the index file it belongs to (row count + checksum): engine.load ignores a list
+        # that was left beside another build of the index
+        with open(paths_file, "w") as f:
+            json.dump({"ntotal": int(index.ntotal), "index_crc32": file_crc32(config.DNN_INDEX_PATH),
+                       "paths": described}, f)
     else:  # descriptions came from somewhere that does not track paths (the cached joblib file, quirk 5.9-5)
         print(f"WARNING: {len(described)} described paths for {index.ntotal} rows: no paths file written")
+        if paths_file.exists():  # an older build's list must not sit beside the new index
+            paths_file.unlink()
     return index
 
 

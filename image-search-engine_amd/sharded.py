@@ -77,6 +77,20 @@ class RcclComm:
         self._n = _n
         self.device = device
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_gpu = dist.get_backend(group) == "nccl"
+        # Local preconditions first (librccl resolves, the device is usable), agreed on across the ranks
+        # BEFORE anyone enters ncclCommInitRank: a rank that cannot get there -- a failed dlopen, a bad
+        # device index -- would leave the others blocked in the rendezvous for good.  Every rank raises
+        # (or none does), so the caller's own agreement step stays in lockstep.
+        pre_err = None
+        try:
+            _n.check(_n.lib.ise_comm_precheck(device.index if device.index is not None else 0))
+        except Exception as e:  # noqa: BLE001 -- agreed on below
+            pre_err = e
+        ok = torch.tensor([0 if pre_err else 1], dtype=torch.int32, device=device if on_gpu else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"RCCL communicator preconditions failed on some rank (this rank: {pre_err!r})")
         buf = ctypes.create_string_buffer(128)
         id_err = None
         if rank == 0:
@@ -85,7 +99,6 @@ class RcclComm:
             except Exception as e:  # noqa: BLE001 -- the broadcast below must still happen: the peers wait in it
                 id_err, buf = e, ctypes.create_string_buffer(128)
         t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        on_gpu = dist.get_backend(group) == "nccl"
         if on_gpu:
             t = t.to(device)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)

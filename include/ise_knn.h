@@ -95,6 +95,19 @@ int ise_index_get_shift(ise_index_t* h, float* mu_host);
  *   took the large-batch GEMM-shaped path (nq >= 64).  Blocks. */
 int ise_index_stats(ise_index_t* h, uint64_t* out4);
 
+/* Short indexes (a batch of <= 16 queries, k + spare candidates <= 32, at most 32 row tiles of 16 rows per
+ * block of the grid: <= 262k rows on an MI355X) are searched by ONE launch -- scan, per-block selection, and
+ * merge (+ exact re-rank) by the last blocks to arrive (csrc/ise_short_scan.hpp): the reference's own regime,
+ * ~1 k images and one query per request (backend/utils.py:309-310, backend/engine.py:50-55).
+ *   out2[0] batches answered that way, out2[1] tail blocks that stopped waiting for the grid (expected 0;
+ *   float32 L2 queries concerned were answered by the exact scan, others came back empty).  Blocks. */
+int ise_index_short_stats(ise_index_t* h, uint64_t* out2);
+
+/* Test / rehearsal knobs ($ISE_FORCE_EXACT, $ISE_NO_DIRECT, $ISE_NO_SHORT, $ISE_SHORT_TPB_MAX,
+ * $ISE_DIRECT_MIN_TILES) are read from the environment when the library is first used and again when
+ * this is called -- never inside a search. */
+int ise_refresh_env_knobs(void);
+
 /* Size every internal workspace for batches of nq queries and k results now (device allocations,
  * fills and the shift refresh otherwise happen inside the first search of that shape), so that a
  * serving loop is allocation-free from its first batch on.  Blocks. */
@@ -142,6 +155,10 @@ int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int64_t nq, int
  * one in-RAM IndexFlat, backend/utils.py:327): ONE all-gather of every rank's packed candidates,
  * issued by RCCL on the caller's stream between the shard scans and the merge -- no host
  * synchronisation, no framework in between.
+ *   ise_comm_precheck    everything ise_comm_create needs that can be checked WITHOUT the other ranks
+ *                        (librccl resolves with every symbol, `device` exists and can be made current):
+ *                        the caller agrees on the outcome across ranks BEFORE any rank enters the
+ *                        rendezvous of ise_comm_create, where a missing peer would block the others
  *   ise_comm_unique_id   rank 0 draws the 128-byte id of a new communicator; the caller hands it to
  *                        the other ranks (any channel; sharded.py uses one torch.distributed broadcast)
  *   ise_comm_create      every rank, collectively: join as `rank` of `world`, one GPU per rank
@@ -150,6 +167,7 @@ int ise_merge_keys_device(const uint64_t* keys_dev, int n_lists, int64_t nq, int
  * librccl is resolved at run time, so the library loads without it; these entry points then
  * return ISE_E_NODEVICE. */
 typedef struct ise_comm ise_comm_t;
+int ise_comm_precheck(int device);
 int ise_comm_unique_id(void* id128);
 int ise_comm_create(ise_comm_t** out, const void* id128, int world, int rank, int device);
 int ise_comm_allgather_keys(ise_comm_t* c, const uint64_t* send_dev, uint64_t* recv_dev,

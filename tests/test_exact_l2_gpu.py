@@ -28,25 +28,46 @@ def faiss():
     return fc
 
 
-class no_direct:
-    """One-query float32 L2 batches skip the filter and run the direct-difference scan alone; with this
-    they take the filtered path like every other batch (ISE_NO_DIRECT, read per call)."""
+class env_knob:
+    """A test knob of the library, set for the block: the library reads its knobs from the environment
+    when ise_refresh_env_knobs() is called (include/ise_knn.h), never inside a search."""
+
+    def __init__(self, name, value="1"):
+        self.name, self.value = name, str(value)
 
     def __enter__(self):
-        os.environ["ISE_NO_DIRECT"] = "1"
+        from image_search_engine_amd import _native as n
+
+        os.environ[self.name] = self.value
+        n.lib.ise_refresh_env_knobs()
 
     def __exit__(self, *a):
-        os.environ.pop("ISE_NO_DIRECT", None)
+        from image_search_engine_amd import _native as n
+
+        os.environ.pop(self.name, None)
+        n.lib.ise_refresh_env_knobs()
 
 
-class forced_exact:
+def no_direct():
+    """One-query float32 L2 batches against LONG indexes skip the filter and run the direct-difference scan
+    alone; with this they take the filtered path like every other batch."""
+    return env_knob("ISE_NO_DIRECT")
+
+
+def forced_exact():
     """Every certificate fails inside the block: the exact fallback scan produces the results."""
+    return env_knob("ISE_FORCE_EXACT")
 
-    def __enter__(self):
-        os.environ["ISE_FORCE_EXACT"] = "1"
 
-    def __exit__(self, *a):
-        os.environ.pop("ISE_FORCE_EXACT", None)
+def force_direct():
+    """One-query float32 L2 batches run the direct-difference scan whatever the index length (by default short
+    indexes are answered by the one-launch filtered kernel instead)."""
+    return env_knob("ISE_DIRECT_MIN_TILES", 1)
+
+
+def no_short():
+    """Short indexes take the streaming kernel + merge launches instead of the one-launch kernel."""
+    return env_knob("ISE_NO_SHORT")
 
 
 def _adversarial(kind, rng, n, d):
@@ -91,11 +112,16 @@ def test_l2_exact_on_adversarial_data(faiss, kind, nq, adds):
     D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
     n_mism = assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2, gap=ko.kth_gap(xb, xq, k, L2))
     assert n_mism == 0 or kind == "two_far_clusters"  # only float32 near-ties may differ, and only there
-    if nq == 1:  # a one-query batch is answered by the direct scan alone; the filtered path returns the same bits
-        assert index.host_stats()["direct_queries"] >= 1
-        with no_direct():
+    assert index.short_stats() == {"short_batches": 2 if adds == "several" else 1, "gave_up": 0}
+    if nq == 1:  # a one-query batch through the direct scan alone and through the streaming kernels: the same bits
+        with force_direct():
+            d0 = index.host_stats()["direct_queries"]
             Df, If = index.search(xq, k)
+            assert index.host_stats()["direct_queries"] == d0 + 1
         assert np.array_equal(If, I) and np.array_equal(Df, D)
+    with no_short():
+        Df, If = index.search(xq, k)
+    assert np.array_equal(If, I) and np.array_equal(Df, D)
     st = index.exact_stats()
     assert st["reranked"] >= nq
     if kind == "two_far_clusters":
@@ -143,6 +169,13 @@ def test_one_query_batches_run_the_direct_scan(faiss, n, d):
     index.add(xb)
     direct0 = index.host_stats()["direct_queries"]
     asked = 0
+    with force_direct():  # (short indexes are answered by the one-launch filtered kernel otherwise: compared below)
+        _one_query_direct_cases(faiss, index, xb, n, d, direct0, asked)
+
+
+def _one_query_direct_cases(faiss, index, xb, n, d, direct0, asked):
+    import torch
+
     for k in (1, 10, 32):
         xq = (xb[min(5, n - 1):min(5, n - 1) + 1] + (np.float32(0.0) if k == 10 else np.float32(0.01))).astype(np.float32)
         D, I = index.search(xq, k)
@@ -152,6 +185,9 @@ def test_one_query_batches_run_the_direct_scan(faiss, n, d):
         if k == 10 and n >= 64:
             assert I[0, 0] == 5 and I[0, 1] == n - 2 and D[0, 0] == 0.0 and D[0, 1] == 0.0
         with no_direct():
+            Df, If = index.search(xq, k)
+        assert np.array_equal(If, I) and np.array_equal(Df, D), (n, d, k)
+        with no_direct(), no_short():
             Df, If = index.search(xq, k)
         assert np.array_equal(If, I) and np.array_equal(Df, D), (n, d, k)
         Dt, It = index.search_torch(torch.from_numpy(xq).cuda(), k)

@@ -407,7 +407,8 @@ def test_config2_cnn_embeddings_to_l2_index_end_to_end():
     D0, I0 = index.search(xb[17:18], 1)
     assert I0[0, 0] == 17 and D0[0, 0] == 0.0
     st = index.exact_stats()
-    assert st["reranked"] == nq and index.host_stats()["direct_queries"] == 1   # the one-query batch ran the direct scan
+    # both batches (nq queries, then one) were answered by one launch of the short-index kernel each
+    assert st["reranked"] == nq + 1 and index.short_stats() == {"short_batches": 2, "gave_up": 0}
 
 
 def test_config2_at_full_size():

@@ -226,7 +226,9 @@ def test_indexer_engine_route_end_to_end_on_gpu(tmp_path, monkeypatch):
     monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", models / "absent.joblib")
     index = indexer.main()
     assert index.ntotal == 39
-    listed = json.loads(engine.paths_file_for(models / "resnet50_dnn_index.faiss").read_text())
+    rec = json.loads(engine.paths_file_for(models / "resnet50_dnn_index.faiss").read_text())
+    listed = rec["paths"]
+    assert rec["ntotal"] == 39 and rec["index_crc32"] == engine.file_crc32(models / "resnet50_dnn_index.faiss")
     assert len(listed) == 39 and str(data / "img_0005.png") not in listed
     saved = (engine.index, engine.images_paths, engine.descriptor)
     try:
@@ -243,6 +245,14 @@ def test_indexer_engine_route_end_to_end_on_gpu(tmp_path, monkeypatch):
             assert [p[0] for p in pred] == sorted(p[0] for p in pred)
     finally:
         engine.index, engine.images_paths, engine.descriptor = saved
+    # a rebuild whose descriptions carry no paths (the cached-descriptions short circuit, quirk 5.9-5) must not
+    # leave the old list beside the new index
+    import joblib
+
+    joblib.dump([np.full((1, 2048), i, np.float32) for i in range(3)], models / "cached.joblib")
+    monkeypatch.setattr(Config, "BOVW_CORNER_DESCRIPTIONS_PATH", models / "cached.joblib")
+    assert indexer.main().ntotal == 3
+    assert not engine.paths_file_for(models / "resnet50_dnn_index.faiss").exists()
 
 
 def test_process_pool_decoder_gives_the_same_descriptions(tmp_path, monkeypatch):
@@ -279,6 +289,27 @@ def test_process_pool_decoder_gives_the_same_descriptions(tmp_path, monkeypatch)
     for name in ("ring", "small slots", "no ring"):
         assert outs[name][1] == outs["threads"][1], name
         assert np.array_equal(outs[name][0], outs["threads"][0]), name
+
+
+def test_paths_file_names_the_index_build_it_belongs_to(tmp_path):
+    """a paths list left beside ANOTHER build of the index (same length, other rows) must not be
+    used: the record carries the index file's row count and checksum, engine.read_paths_file checks both; the
+    first format (a bare list) is still read, checked for its length only."""
+    from image_search_engine_amd import engine
+
+    idx = tmp_path / "x.faiss"
+    idx.write_bytes(b"index build one")
+    pf = engine.paths_file_for(idx)
+    pf.write_text(json.dumps({"ntotal": 2, "index_crc32": engine.file_crc32(idx), "paths": ["a.png", "b.png"]}))
+    assert [str(p) for p in engine.read_paths_file(idx, 2)] == ["a.png", "b.png"]
+    assert engine.read_paths_file(idx, 3) is None                      # another row count
+    idx.write_bytes(b"index build two")                                # same length list, another index file
+    assert engine.read_paths_file(idx, 2) is None
+    pf.write_text(json.dumps(["a.png", "b.png"]))                      # first format
+    assert [str(p) for p in engine.read_paths_file(idx, 2)] == ["a.png", "b.png"]
+    assert engine.read_paths_file(idx, 5) is None
+    pf.unlink()
+    assert engine.read_paths_file(idx, 2) is None
 
 
 def test_runs_of_broken_files_never_hand_out_a_live_ring_slot(tmp_path, monkeypatch):
