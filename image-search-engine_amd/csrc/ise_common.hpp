@@ -86,7 +86,8 @@ struct LdsAttrOnce {
         if (done.load(std::memory_order_acquire) & bit) return;
         std::lock_guard<std::mutex> lk(mu);
         if (done.load(std::memory_order_relaxed) & bit) return;
-        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+            (void)hipGetLastError();  // a launch that needs the attribute then fails with its own error
         done.fetch_or(bit, std::memory_order_release);
     }
 };

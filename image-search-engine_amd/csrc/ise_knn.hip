@@ -106,8 +106,6 @@ struct ise_index {
         int* fl_list = nullptr;   // [fl_elems] the listed queries
         size_t fl_elems = 0;
         uint32_t fl_seq = 0;      // bumped per rerank launch, never reset while fl_state lives
-        unsigned int* arrive = nullptr;  // short-index kernel: monotonic count of blocks that have written their lists
-        unsigned int arrive_count = 0;   // its value once every launch enqueued so far has run
         hipEvent_t done = nullptr;
         bool used = false;
         hipStream_t last_stream = nullptr;  // valid when used
@@ -144,7 +142,7 @@ struct ise_index {
     int cq_leaders = 0;
     unsigned long long cq_batches = 0, cq_requests = 0;
     unsigned long long direct_queries = 0;  // queries answered by the direct small-batch scan (under mu_)
-    unsigned long long short_batches = 0;   // batches answered by one launch of the short-index kernel (under mu_)
+    unsigned long long short_batches = 0;   // batches whose scan was the short-index kernel (under mu_)
     int num_cu = 256;
     std::mutex mu_;
 };
@@ -255,7 +253,6 @@ static void free_all(ise_index* h) {
         if (w.gemm) (void)hipFree(w.gemm);
         if (w.fl_state) (void)hipFree(w.fl_state);
         if (w.fl_list) (void)hipFree(w.fl_list);
-        if (w.arrive) (void)hipFree(w.arrive);
         if (w.done) (void)hipEventDestroy(w.done);
         w = ise_index::WorkSlot();
     }
@@ -542,11 +539,11 @@ static void launch_scan(const ise_index* h, int ch, int waves, int T, dim3 grid,
     else ise_launch_scan_f32_plain(ch, waves, T, grid, lds, st, sp);
 }
 
-static void launch_short(const ise_index* h, int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp,
-                         const ShortTailParams& tp) {
-    if (h->storage == ISE_STORE_BF16) ise_launch_short_bf16(ch, grid, lds, st, sp, tp);
-    else if (uses_shift(h)) ise_launch_short_f32_shift(ch, grid, lds, st, sp, tp);
-    else ise_launch_short_f32_plain(ch, grid, lds, st, sp, tp);
+static void launch_short(const ise_index* h, int ch, int waves, int bpc, int grid, size_t lds, hipStream_t st,
+                         const ScanParams& sp, const ShortParams& tp) {
+    if (h->storage == ISE_STORE_BF16) ise_launch_short_bf16(ch, waves, bpc, grid, lds, st, sp, tp);
+    else if (uses_shift(h)) ise_launch_short_f32_shift(ch, waves, bpc, grid, lds, st, sp, tp);
+    else ise_launch_short_f32_plain(ch, waves, bpc, grid, lds, st, sp, tp);
 }
 
 struct ScanPlan {
@@ -556,7 +553,8 @@ struct ScanPlan {
     int kc;      // keys per query the scan + merge stage selects: k, or k + extra candidates when exact
     bool gemm;   // the batch takes the large-batch path (ise_gemm_scan.hpp): the slot also holds its buffers
     size_t gemm_bytes;
-    bool short_;  // the batch runs as ONE launch of the short-index kernel (ise_short_scan.hpp)
+    bool short_;  // the batch's scan is the short-index kernel (ise_short_scan.hpp)
+    int short_bpc;  // ... with this many blocks per CU
 };
 
 // candidates kept beyond k on the exact path: enough that the certificate holds on data whose
@@ -688,24 +686,37 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
     pl->gemm = false;
     pl->gemm_bytes = 0;
     pl->short_ = false;
-    // Short indexes, one query tile, one pass: the whole batch is ONE launch of short_scan_kernel (scores dumped
-    // to LDS, one selection per block, merge + re-rank by the last blocks to arrive).  Two 8-wave blocks per CU
-    // when their LDS images fit side by side, else one; a block's rows must fit the selection (SHORT_TPB_MAX tiles).
+    pl->short_bpc = 0;
+    // Short indexes, one query tile, one pass: short_scan_kernel (scores dumped to LDS, one selection per block;
+    // ise_short_scan.hpp) writes the per-block lists instead of scan_kernel.  Two 8-wave blocks per CU when their
+    // LDS images fit side by side, else one; a block's rows must fit the selection (SHORT_TPB_MAX tiles).
     if (allow_short && nq <= 16 && pl->kc <= pl->kpass && h->n > 0 && !knobs().no_short.load(std::memory_order_relaxed)) {
         int tpb_max = knobs().short_tpb_max.load(std::memory_order_relaxed);
         if (tpb_max <= 0 || tpb_max > SHORT_TPB_MAX) tpb_max = SHORT_TPB_MAX;
         const int S = qs_stride_for(h);
-        for (int bpc = 2; bpc >= 1 && !pl->short_; bpc--) {
-            int nbs = std::min(h->num_cu * bpc, (pl->tiles_total + SHORT_W - 1) / SHORT_W);
-            nbs = std::max(1, std::min(nbs, MERGE_LISTS_MAX));
+        // shapes tried in order: one 16-wave block per CU (the queries are staged once per CU, one query per
+        // wave in the selection, half the lists for the merge: 36.3 us per step at 100k x 512 against 42.0 with two
+        // 8-wave blocks per CU and 44.2 with three), two 8-wave blocks per CU (up to 262k rows), one 8-wave block
+        // per CU (long rows: the query tile alone takes most of the LDS).  The row tiles are split evenly over the
+        // blocks: the stream is bound per CU, so every CU gets the same bytes (within one tile).
+        static const int shapes[3][2] = {{16, 1}, {8, 2}, {8, 1}};  // waves, blocks per CU
+        int first = 0;
+#ifdef ISE_ABLATE
+        if (const char* e = getenv("ISE_SHORT_SHAPE")) first = std::max(0, std::min(2, atoi(e)));  // dev: skip shapes
+#endif
+        for (int si = first; si < 3 && !pl->short_; si++) {
+            const int wv = shapes[si][0], bpc = shapes[si][1];
+            int nbs = std::max(1, std::min(h->num_cu * bpc, (pl->tiles_total + wv - 1) / wv));
+            nbs = std::min(nbs, MERGE_LISTS_MAX);
             const int tpb = (pl->tiles_total + nbs - 1) / nbs;
-            const size_t lds = short_lds_layout(S, tpb, h->dp, pl->kc) + 64 /* the kernel's static words */;
+            const size_t lds = short_lds_layout(S, tpb, wv);
             if (tpb <= tpb_max && lds <= (size_t)LDS_LIMIT / bpc) {
                 pl->short_ = true;
                 pl->nblocks = nbs;
                 pl->tiles_per_block = tpb;
-                pl->lds = lds - 64;
-                pl->waves = SHORT_W;
+                pl->lds = lds;
+                pl->waves = wv;
+                pl->short_bpc = bpc;
                 pl->T = 1;
                 pl->nqt = 1;
                 pl->ch = std::min(chunk_steps(h), 4);
@@ -763,12 +774,6 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
             w->gemm_bytes = needg;
             *changed = true;
         }
-    }
-    if (pl.short_ && !w->arrive) {
-        HIP_TRY(hipMalloc(&w->arrive, 256));
-        HIP_TRY(hipMemset(w->arrive, 0, 256));
-        w->arrive_count = 0;
-        *changed = true;
     }
     if (pl.exact) {
         if (!w->fl_state) {
@@ -910,8 +915,8 @@ static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, con
     // one query only: two to four queries are VALU-bound here (380-520 us) and faster through the filter (356 us)
     // (ISE_FORCE_EXACT asks for the filtered path's fallback to be exercised: it implies the filtered path)
     if (!pl.exact || nq != 1 || k > KPASS_MAX || h->n <= 0 || !w->fl_state || no_direct() || force_exact()) return false;
-    // short indexes: the one-launch filtered search (ise_short_scan.hpp) is faster than this scan's serial tail
-    // (100k x 512: 60 us direct); $ISE_DIRECT_MIN_TILES moves the crossover for experiments
+    // short indexes: the filtered search behind the short-index kernel (ise_short_scan.hpp) is faster than this
+    // scan's serial tail (100k x 512: 56.9 us per step direct); $ISE_DIRECT_MIN_TILES moves the crossover
     const int min_tiles = knobs().direct_min_tiles.load(std::memory_order_relaxed);
     if (pl.short_ && (min_tiles <= 0 || pl.tiles_total < min_tiles)) return false;
     // >= 64 rows per block (4 waves x XR rows x 4 steps), at most the merge's list count
@@ -1135,29 +1140,26 @@ static int scan_path_enqueue(ise_index* h, ise_index::WorkSlot* w, const ScanPla
     xp.force_fail = force_exact() ? 1 : 0;
     xp.tau_bound = nullptr;
 
-    if (pl.short_) {  // one launch: scan + per-block selection + merge (+ exact re-rank) by the last blocks to arrive
+    if (pl.short_) {  // short index: stream + per-block selection in one pass without boot or thresholds
         if (gate) return fail(ISE_E_INVALID, "internal: a gated rerun was planned for the short-index kernel");
-        ShortTailParams tp;
-        tp.mp = mp;
-        tp.mp.qt = 16; tp.mp.stride_list = 16ll * pl.kpass; tp.mp.stride_qtile = (long long)pl.nblocks * 16 * pl.kpass;
-        tp.mp.dbg = nullptr;
-        tp.xp = xp;
-        tp.arrive = w->arrive;
-        tp.arrive_base = w->arrive_count;
-        tp.gave_up = h->stats_dev + 2;
-        w->arrive_count += (unsigned int)pl.nblocks;
+        ShortParams shp;
+        shp.even_split = 1;
         h->short_batches++;
-        if (pl.exact) {
-            if ((rc = next_fl_seq(w, st, &tp.xp.seq))) return rc;
-            tp.mp.D = nullptr; tp.mp.I = nullptr; tp.mp.keys_out = nullptr;
-        } else {
-            tp.mp.D = D_dev; tp.mp.I = I_dev; tp.mp.keys_out = keys_out;
-        }
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
-        launch_short(h, pl.ch, pl.nblocks, pl.lds, st, sp, tp);
+        launch_short(h, pl.ch, pl.waves, pl.short_bpc, pl.nblocks, pl.lds, st, sp, shp);
         HIP_TRY(hipGetLastError());
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
-        if (pl.exact && (rc = enqueue_exact_fallback(h, w, pl, tp.xp, nq, st))) return rc;
+        if (pl.exact) {
+            if ((rc = next_fl_seq(w, st, &xp.seq))) return rc;
+            mp.D = nullptr; mp.I = nullptr; mp.keys_out = nullptr;
+            launch_merge<true>((unsigned)nq, rerank_lds_bytes(h->dp, pl.kc), st, mp, xp);
+            HIP_TRY(hipGetLastError());
+            if ((rc = enqueue_exact_fallback(h, w, pl, xp, nq, st))) return rc;
+        } else {
+            mp.D = D_dev; mp.I = I_dev; mp.keys_out = keys_out;
+            launch_merge<false>((unsigned)nq, 0, st, mp, xp);
+            HIP_TRY(hipGetLastError());
+        }
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e2, st));
         return ISE_OK;
     }
@@ -1610,15 +1612,10 @@ extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq,
     return ISE_OK;
 }
 
-extern "C" int ise_index_short_stats(ise_index_t* h, uint64_t* out2) {
-    if (!h || !out2) return fail(ISE_E_INVALID, "NULL argument");
+extern "C" int ise_index_short_stats(ise_index_t* h, uint64_t* out1) {
+    if (!h || !out1) return fail(ISE_E_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu_);
-    DeviceGuard gd(h->device);
-    HIP_TRY(hipDeviceSynchronize());
-    unsigned long long gave_up = 0;
-    HIP_TRY(hipMemcpy(&gave_up, h->stats_dev + 2, sizeof(gave_up), hipMemcpyDeviceToHost));
-    out2[0] = h->short_batches;
-    out2[1] = gave_up;
+    out1[0] = h->short_batches;
     return ISE_OK;
 }
 

@@ -6,6 +6,6 @@ void ise_launch_scan_bf16(int ch, int waves, int T, dim3 grid, size_t lds, hipSt
     launch_scan_v<true, false>(ch, waves, T, grid, lds, st, sp);
 }
 
-void ise_launch_short_bf16(int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortTailParams& tp) {
-    launch_short_v<true, false, false>(ch, grid, lds, st, sp, tp);
+void ise_launch_short_bf16(int ch, int waves, int bpc, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp) {
+    launch_short_v<true, false>(ch, waves, bpc, grid, lds, st, sp, tp);
 }

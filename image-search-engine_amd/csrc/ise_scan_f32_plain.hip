@@ -6,6 +6,6 @@ void ise_launch_scan_f32_plain(int ch, int waves, int T, dim3 grid, size_t lds, 
     launch_scan_v<false, false>(ch, waves, T, grid, lds, st, sp);
 }
 
-void ise_launch_short_f32_plain(int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortTailParams& tp) {
-    launch_short_v<false, false, false>(ch, grid, lds, st, sp, tp);
+void ise_launch_short_f32_plain(int ch, int waves, int bpc, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp) {
+    launch_short_v<false, false>(ch, waves, bpc, grid, lds, st, sp, tp);
 }

@@ -1,103 +1,99 @@
-// ise_short_scan.hpp -- the whole search of one batch of <= 16 queries against a SHORT index in ONE launch.
+// ise_short_scan.hpp -- the scan of one batch of <= 16 queries against a SHORT index.
 //
 // The reference's own regime is short indexes (about 1 k images, backend/utils.py:309-310; one query per
 // request, backend/engine.py:50-55); BASELINE config 2 is 100k x 512 and every rank of the 8-GPU run scans a
-// 125k-row shard.  There a wave of scan_kernel (ise_scan.hpp) owns one or two row tiles: its boot (dump, two
-// barriers, windowed cut -- with nothing in flight meanwhile), its final selection and the two launches behind
-// it (merge + re-rank, the exact scan's gate) ARE the search: 45.8 + 10.5 + 3.9 us at 100k x 512 where the
-// rows stream in 29 us (profiles/r03/README.md).  This kernel keeps the row stream, the MFMA tile and the
-// arithmetic of scan_kernel -- the keys it selects are the same keys, bit for bit -- and replaces the rest:
+// 125k-row shard.  There a wave of scan_kernel (ise_scan.hpp) owns one or two row tiles, and its top-k
+// bookkeeping IS the kernel: the boot (dump, two barriers, a windowed cut -- nothing in flight meanwhile) sits
+// in the middle of the stream and the final selection behind it: 45.8 us at 100k x 512, where a kernel that
+// only reads the rows in the same shape takes 30 (scripts/microbench/tile_read_bw.hip).  This kernel keeps
+// the row stream, the MFMA tile and the arithmetic of scan_kernel -- the per-block lists it writes hold the
+// same keys, bit for bit, and go to the same merge_kernel -- and replaces the bookkeeping:
 //
 //   stream   a wave runs its row tiles back to back; a tile's 16 x 16 scores go to LDS as plain floats
 //            (one 16-byte store per lane and tile: the row id is the slot index).  No threshold, no lists,
-//            no barrier until the block's rows are done, and R - 1 chunks are requested BEFORE the queries
-//            are staged, so the stream also covers the staging.
-//   select   one barrier; per query one wave rebuilds the keys of the block's rows and selects the exact
-//            sorted top k (wave_select) -> the block's list in `part`, as scan_kernel leaves it.
-//   tail     every block takes a ticket (one agent-scope add behind its drained stores and a release).
-//            The holders of the LAST min(nq, blocks) tickets are the tail workers, one query each: a worker
-//            waits until all blocks have arrived (a relaxed poll; the holder of the last ticket does not
-//            wait at all), acquires, and runs what merge_kernel runs: the 8-wave merge of the per-block lists
-//            and, for float32 L2, the direct-difference re-rank with its certificate (ise_exact.hpp).
+//            no barrier until the block's rows are done; R - 1 chunks are requested BEFORE the queries are
+//            staged, so the stream also covers the staging.
+//   select   one barrier; per query one wave finds a threshold on the 32-bit scores (the k-th smallest of the
+//            64 lane minima bounds the k-th smallest score), turns the rows at or below it -- about k + a few
+//            -- into 64-bit keys and ranks those: the exact sorted top k -> the block's list in `part`.
 //
-// Progress: a waiting worker holds one block slot; at most 16 per launch wait and at most NWS launches are
-// in flight (one per workspace slot), so waiters hold at most 96 of the chip's >= 512 slots and the blocks
-// they wait for are always scheduled.  The wait is bounded all the same: a worker that gives up puts its
-// query on the exact scan's fallback list (float32 L2: the gated exact scan then answers it, the result stays
-// exact), or emits an empty result and counts the event (inner product / bf16: no fallback exists).
-//
-// The arrival counter is monotonic (never reset): the host passes its value before the launch.
+// Tried and NOT adopted (profiles/r03/README.md): the merge + exact re-rank folded into this launch (every
+// block takes a ticket behind a release; the holders of the last nq tickets wait for the others, acquire, and
+// each run merge_kernel's body for one query).  Correct (every parity test passed with it), but the tail cost
+// 11 us inside the kernel against 10.5 us + a 1.5 us launch boundary as its own launch, the arrive sequence
+// another 3 us for every block, and the launch held one of the four hardware queues for its whole 62 us while
+// only 16 blocks worked: 43.8 us per step against 39.0 for scan + merge launches.
 #pragma once
 #include "ise_common.hpp"
-#include "ise_exact.hpp"
-#include "ise_merge.hpp"
 #include "ise_scan_params.hpp"
 #include "ise_select.hpp"
 
-#define SHORT_W 8          /* waves per block: the tail is merge_kernel's 8-wave merge */
+#define SHORT_W_MAX 16     /* waves per block: 16 (one block per CU) or 8 (two) */
 #define SHORT_KPL 8        /* keys per lane of the block selection: <= 512 rows (32 tiles) per block */
 #define SHORT_TPB_MAX (SHORT_KPL * 64 / 16)
-#define SHORT_WAIT_TICKS 200000000ull /* 2 s of the 100 MHz clock: a worker gives up waiting for the other blocks */
 
-struct ShortTailParams {
-    MergeParams mp;            // lists = the per-block lists this launch writes (n_lists = gridDim.x, k = keys per list)
-    ExactParams xp;            // RERANK instantiations only
-    unsigned int* arrive;      // the slot's arrival counter (monotonic)
-    unsigned int arrive_base;  // its value before this launch
-    unsigned long long* gave_up;  // counts tail workers that stopped waiting (never, in practice)
+struct ShortParams {
+    int even_split;  // 1 = the row tiles are split evenly over the blocks instead of tiles_per_block each
 };
 
 // dump row stride in floats: whole 32-float groups + 4, so that the 8 lanes of a 16-byte store group
 // (8 queries, same rows) fall into different banks
 __host__ __device__ constexpr int short_dump_stride(int tiles_per_block) { return (tiles_per_block * 16 + 31) / 32 * 32 + 4; }
-// bytes of the tail's LDS image: merge scratch | merged keys | rerank image (query, candidates, exact keys)
-__host__ __device__ constexpr size_t short_tail_bytes(int dp, int kc) {
-    return sizeof(MergeFastScratch) + (size_t)MERGE_FAST_K * 8 + rerank_lds_bytes(dp, kc) + 16;
-}
-__host__ __device__ constexpr size_t short_lds_layout(int S, int tiles_per_block, int dp, int kc) {
+__host__ __device__ constexpr size_t short_lds_layout(int S, int tiles_per_block, int waves) {
     const size_t head = (size_t)S * 4 + 16 * ((size_t)S * 4) + 16 * 4;  // mus | qs | xn
-    const size_t dump = (size_t)16 * short_dump_stride(tiles_per_block) * 4;
-    const size_t tail = short_tail_bytes(dp, kc);
-    return head + (dump > tail ? dump : tail);
+    const size_t dump = (size_t)16 * short_dump_stride(tiles_per_block) * 4 + (size_t)waves * 64 * 8;  // + selection scratch
+    return head + dump;
 }
 
+#ifdef ISE_ABLATE
+#define SABL(bit) (p.ablate & (bit))
+#else
+#define SABL(bit) 0
+#endif
 #ifdef ISE_ABLATE
 #define SSTAMP(i)                                                                                      \
     do {                                                                                               \
         if (p.stamps && lane == 0)                                                                     \
-            p.stamps[((size_t)blockIdx.x * SHORT_W + w) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+            p.stamps[((size_t)blockIdx.x * W + w) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define SSTAMP(i) do {} while (0)
 #endif
 
 // CH: k-steps per register chunk; R: chunks in the ring (R - 1 requested ahead of the one computed)
-template <int CH, int R, bool BF16, bool SHIFT, bool RERANK>
-__global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanParams p, const ShortTailParams tp) {
+// WPS: waves per SIMD the register budget is sized for (blocks per CU * W / 4)
+template <int CH, int R, int W, int WPS, bool BF16, bool SHIFT>
+__global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParams p, const ShortParams tp) {
     static_assert(!(BF16 && SHIFT), "the shift is applied to fp32 rows only");
-    static_assert(!RERANK || SHIFT, "the re-rank belongs to the float32 L2 search");
-    constexpr int W = SHORT_W;
     constexpr int BLOCK_THREADS = W * 64;
     constexpr int NQ = 16;
-    constexpr int TPR = BLOCK_THREADS / 16;  // threads staging one query row
+    // 32 threads stage one query row, whatever the block width (a 16-wave block stages with its first 8 waves):
+    // the sum of squares |x|^2 then has ONE summation order -- the one of scan_kernel's 8-wave blocks -- and
+    // the bf16 L2 distances, which carry it, come out the same bits from every kernel
+    constexpr int TPR = 32;
     extern __shared__ __align__(16) unsigned char smem[];
     const int S = p.qs_stride;
     float* mus = reinterpret_cast<float*>(smem);   // [S] shift vector (SHIFT only)
     float* qs = mus + S;                           // [NQ][S]
     float* xn = qs + NQ * S;                       // [NQ]
-    float* dump = xn + NQ;                         // [NQ][DS] scores of the block's rows; the tail's image later
-    unsigned char* tail_mem = reinterpret_cast<unsigned char*>(dump);
-    __shared__ unsigned int s_ticket;
-    __shared__ int s_ok;
+    float* dump = xn + NQ;                         // [NQ][DS] scores of the block's rows
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as a scalar: the per-query loops below then branch on SGPRs (hipcc otherwise treats
+    // tid >> 6 as divergent and compiles them with exec masks and spilled scalar registers)
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool stager = tid < 16 * TPR;
     const int c = lane & 15, g = lane >> 4;
     const int nqt = min(NQ, p.nq);
     const int k = p.k;
     const int nsteps = p.row_slots >> 2;
-    // even split of the row tiles over the blocks
-    const int t0 = (int)((long long)blockIdx.x * p.tiles_total / gridDim.x);
-    const int t1 = (int)((long long)(blockIdx.x + 1) * p.tiles_total / gridDim.x);
+    // a block owns tiles_per_block = 8 r consecutive row tiles, its waves interleave: r tiles per wave, every
+    // wave of the grid (but the last block's) the same number -- a wave that owns one tile more than the others
+    // finishes a whole latency-bound tile time after them
+    const int t0 = tp.even_split ? (int)((long long)blockIdx.x * p.tiles_total / gridDim.x) : blockIdx.x * p.tiles_per_block;
+    const int t1 = tp.even_split ? (int)((long long)(blockIdx.x + 1) * p.tiles_total / gridDim.x)
+                                 : min(t0 + p.tiles_per_block, p.tiles_total);
+    // (even: every block -- every CU -- the same bytes, within a tile; the stream is bound per CU)
     const int DS = short_dump_stride(p.tiles_per_block);
     const bool l2 = p.metric == ISE_METRIC_L2;
     SSTAMP(0);
@@ -105,6 +101,7 @@ __global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanP
     auto load_chunk = [&](f32x4(&a)[CH], int tile, int s0) {
         const char* base = static_cast<const char*>(p.xb) +
                            ((((size_t)tile * 16 + c) * p.row_slots + 4 * s0 + g) << 4);
+        if (SABL(128)) return;  // dev: no index loads
 #pragma unroll
         for (int s = 0; s < CH; s++) a[s] = *reinterpret_cast<const f32x4*>(base + 64 * s);
     };
@@ -121,10 +118,15 @@ __global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanP
     const bool vec_q = (p.d & (BF16 ? 7 : 3)) == 0 && ((reinterpret_cast<uintptr_t>(p.q) & 15) == 0) &&
                        S4 <= TPR * QVS;
     f32x4 qv[QV];
-    {
+    f32x4 mu1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (stager) {
         const int cc = tid / TPR, t = tid % TPR;
         const bool rowok = cc < nqt;
         const float* src = p.q + (size_t)(rowok ? cc : 0) * p.d;
+        // the shift vector goes through LDS (one slot per thread, S4 <= 256 here) and the queries read it from
+        // there: held in registers per thread (8 slots) it would cost the ring a chunk.  Requested first: waits
+        // are counted in issue order
+        if (SHIFT && vec_q && tid < dslots) mu1 = *reinterpret_cast<const f32x4*>(p.mu + 4 * tid);
         if (vec_q) {
 #pragma unroll
             for (int i = 0; i < QVS; i++) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanP
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- the ring: R - 1 chunks requested now, so the row stream runs while the queries are staged
-    const bool has_work = (t0 + w) < t1;
+    const bool has_work = (t0 + w) < t1 && !SABL(16);
     f32x4 A[R][CH];
     int ltile = t0 + w, ls0 = 0;
     auto advance_load = [&]() {
@@ -157,14 +159,17 @@ __global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanP
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- query staging, step 2: into LDS (zero padded to NQ x S units) with |x|^2; the shift vector is read
-    // slot by slot here (L2-resident), not held in registers beside the ring
+    // ---- query staging, step 2: into LDS (zero padded to NQ x S units) with |x|^2
+    if (SHIFT && vec_q) {
+        if (tid < S4) *reinterpret_cast<f32x4*>(mus + 4 * tid) = mu1;
+        __syncthreads();
+    }
     auto to_bf16_pair = [](float lo, float hi) -> uint32_t {
         const __bf16 a = (__bf16)lo, b = (__bf16)hi;
         return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
     };
     auto bf16_round = [](float v) -> float { return (float)(__bf16)v; };
-    {
+    if (stager) {
         const int cc = tid / TPR, t = tid % TPR;
         float sn = 0.f;
         if (vec_q) {
@@ -188,12 +193,7 @@ __global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanP
                         }
                     } else {
                         f32x4 v = qv[i];
-                        if (SHIFT) {
-                            f32x4 m = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (j4 < dslots) m = *reinterpret_cast<const f32x4*>(p.mu + 4 * j4);
-                            if (cc < nqt) v = v - m;  // padding rows stay zero
-                            if (cc == 0) *reinterpret_cast<f32x4*>(mus + 4 * j4) = m;
-                        }
+                        if (SHIFT && cc < nqt) v = v - *reinterpret_cast<const f32x4*>(mus + 4 * j4);  // padding rows stay zero
                         *reinterpret_cast<f32x4*>(qs + cc * S + 4 * j4) = v;
                         sn = fmaf(v[0], v[0], sn);
                         sn = fmaf(v[1], v[1], sn);
@@ -247,6 +247,10 @@ __global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanP
     auto compute_chunk = [&](const f32x4(&a)[CH], int s0, int next_first_step) {
 #pragma unroll
         for (int s = 0; s < CH; s++) {
+            if (SABL(64)) {  // dev: no LDS reads, no MFMA -- the loaded data is only summed
+                acc0 += a[s];
+                continue;
+            }
             f32x4 bnext;
             load_b(bnext, s + 1 < CH ? s0 + s + 1 : next_first_step);
             f32x4 as = a[s];
@@ -283,10 +287,17 @@ __global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanP
                         const f32x4 dot = acc0 + acc1;
                         acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
                         acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        // rows past the end of the index and scores that may not enter (>= FLT_MAX, NaN: Faiss's
+                        // strict gate) are dumped as +inf: the selection then compares plain floats
                         f32x4 sc;
+                        const long long row0 = (long long)tile * 16 + 4 * g;
 #pragma unroll
-                        for (int jj = 0; jj < 4; jj++) sc[jj] = score(dot[jj], yn[jj]);
+                        for (int jj = 0; jj < 4; jj++) {
+                            const float v = score(dot[jj], yn[jj]);
+                            sc[jj] = (row0 + jj < p.n && v < FLT_MAX) ? v : __builtin_inff();
+                        }
                         *reinterpret_cast<f32x4*>(dump + (size_t)c * DS + (tile - t0) * 16 + 4 * g) = sc;
+                        if (tile == t0 + w) SSTAMP(8);
                     }
                     done = ntile >= t1;
                     tile = ntile; s0 = ns0;
@@ -298,101 +309,152 @@ __global__ __launch_bounds__(SHORT_W * 64, 4) void short_scan_kernel(const ScanP
     __syncthreads();
     SSTAMP(3);
 
-    // ---- select: per query the exact sorted top k of the block's rows -> the block's list
+    // ---- select: per query the exact sorted top k of the block's rows -> the block's list.
+    // All 16 waves of a CU reach this point together and share the SIMDs' issue slots, so what counts is the
+    // instruction count (a 64-bit quickselect over all rows: 6 us per query; a 64-step rank of the lane minima
+    // in front of wave_select: 2.7 us).  Threshold first, on plain floats: a lane holds up to SHORT_KPL scores
+    // of the query; the k-th smallest of the 64 LANE MINIMA (64 distinct rows; found by a ballot quickselect)
+    // bounds the k-th smallest score from above, so only the rows at or below it -- about k + a few -- become
+    // 64-bit keys (ord(score) << 32 | row id) and are ranked, all pairs, one key per lane.  More than 64
+    // survivors (hundreds of equal rows): the general selection.
     const int nkeys = (t1 - t0) * 16;
-    for (int qq = w; qq < NQ; qq += W) {
-        u64 kk[SHORT_KPL];
-#pragma unroll
-        for (int e = 0; e < SHORT_KPL; e++) {
-            kk[e] = KEY_PAD;
-            const int idx = lane + 64 * e;
-            if (idx < nkeys) {
-                const float sc = dump[(size_t)qq * DS + idx];
-                const long long row = (long long)t0 * 16 + idx;
-                const bool ok = row < p.n && sc < FLT_MAX && qq < nqt;
-                if (ok) kk[e] = ((u64)ord_f32(sc) << 32) | (uint32_t)((uint32_t)row + p.id_base);
-            }
-        }
+    const int ne = (nkeys + 63) >> 6;
+    u64* sel = reinterpret_cast<u64*>(dump + (size_t)NQ * DS) + w * 64;  // [W][64] compaction scratch behind the dump
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    const float INF = __builtin_inff();
+    for (int qq = w; qq < NQ && !SABL(4); qq += W) {
         u64* out = p.part + ((size_t)blockIdx.x * NQ + qq) * k;
-        u64 kth_unused;
-        const int nw = wave_select<SHORT_KPL>(kk, nkeys, k, out, &kth_unused);
-        if (lane >= nw && lane < k) out[lane] = KEY_PAD;  // k <= KB_MAX <= 64
-    }
-    SSTAMP(4);
-
-    // ---- arrive: this block's lists are visible at agent scope before its ticket is
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have left
-    __syncthreads();                                    // ... and every wave's; the dump is dead from here on
-    const unsigned int nb = gridDim.x;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ticket = __hip_atomic_fetch_add(tp.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tp.arrive_base;
-    }
-    __syncthreads();
-    const unsigned int ticket = s_ticket;
-    const unsigned int nwork = (unsigned int)p.nq < nb ? (unsigned int)p.nq : nb;
-    if (ticket < nb - nwork) return;
-    SSTAMP(5);
-
-    // ---- tail worker: wait for every block's lists, then merge (+ re-rank) the queries worker, worker + nwork, ...
-    if (tid == 0) {
-        int ok = 1;
-        if (ticket != nb - 1) {  // the holder of the last ticket knows that everybody has arrived
-            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-            while (__hip_atomic_load(tp.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tp.arrive_base < nb) {
-                __builtin_amdgcn_s_sleep(4);
-                if (__builtin_amdgcn_s_memrealtime() - t_start > SHORT_WAIT_TICKS) { ok = 0; break; }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ok = ok;
-    }
-    __syncthreads();
-    SSTAMP(6);
-    MergeFastScratch& fast = *reinterpret_cast<MergeFastScratch*>(tail_mem);
-    u64* res = reinterpret_cast<u64*>(tail_mem + sizeof(MergeFastScratch));                   // [MERGE_FAST_K]
-    unsigned char* rr = tail_mem + ((sizeof(MergeFastScratch) + MERGE_FAST_K * 8 + 15) & ~(size_t)15);  // rerank image
-    for (int q = (int)(ticket - (nb - nwork)); q < p.nq; q += (int)nwork) {
-        if (!s_ok) {  // gave up waiting (see the header): never a silently wrong answer
-            if (tid == 0) {
-                if (tp.gave_up) atomicAdd(tp.gave_up, 1ull);
-                if (RERANK) fallback_list_push(tp.xp, q);
-            }
-            if (!RERANK && tid < tp.mp.k) emit_result(tp.mp, (size_t)q * tp.mp.k + tid, KEY_PAD);
+        if (qq >= nqt) {  // a padding query of the tile: an empty list (the merge never reads it)
+            if (lane < k) out[lane] = KEY_PAD;
             continue;
         }
-        const u64* base = tp.mp.lists + (size_t)q * tp.mp.k;
-        if (RERANK) {
-            u64* kin = reinterpret_cast<u64*>(rr + (size_t)tp.xp.dp * 4);
-            rerank_stage_query<BLOCK_THREADS>(tp.xp, q, rr);  // its loads fly while the lists are merged
-            merge_waves(tp.mp, base, fast, kin);
-            rerank_block<BLOCK_THREADS>(tp.xp, q, rr, nullptr);  // starts with a block barrier
-        } else {
-            merge_waves(tp.mp, base, fast, res);
-            if (tid < tp.mp.k) emit_result(tp.mp, (size_t)q * tp.mp.k + tid, res[tid]);
+        float v[SHORT_KPL];
+        float mn = INF;
+#pragma unroll
+        for (int e = 0; e < SHORT_KPL; e++) {
+            v[e] = INF;
+            if (e < ne) {
+                const int idx = lane + 64 * e;
+                if (idx < nkeys) v[e] = dump[(size_t)qq * DS + idx];
+                mn = fminf(mn, v[e]);
+            }
         }
-        __syncthreads();  // the image is reused by the worker's next query
+        if (qq == w) SSTAMP(9);
+        // T = the k-th smallest lane minimum (by value); fewer than k lanes with a row: every row stays
+        float T = FLT_MAX;
+        if (__popcll(__ballot(mn < INF)) >= k) {
+            float L = -INF, H = INF;  // the target lies in [L, H]; lanes strictly inside are pivot candidates
+            for (int round = 0;; round++) {
+                const u64 m = __ballot(mn > L && mn < H);
+                if (!m) {  // nothing strictly inside: the target is one of the bounds
+                    T = __popcll(__ballot(mn <= L)) >= k ? L : H;
+                    break;
+                }
+                const int rot = (round * 23 + 7) & 63;
+                const u64 hi = (m >> rot) << rot;
+                const float P = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn),
+                                                                                    __ffsll((long long)(hi ? hi : m)) - 1));
+                const int c_lt = __popcll(__ballot(mn < P)), c_le = __popcll(__ballot(mn <= P));
+                if (c_lt < k && c_le >= k) {
+                    T = P;
+                    break;
+                }
+                if (c_lt >= k) H = P;
+                else L = P;
+            }
+        }
+        if (qq == w) SSTAMP(10);
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < SHORT_KPL; e++) {
+            if (e < ne) {
+                const bool keep = v[e] <= T;  // +inf (no row) never: T <= FLT_MAX
+                const u64 m = __ballot(keep);
+                const int pos = cnt + __popcll(m & lt_mask);
+                if (keep && pos < 64)
+                    sel[pos] = ((u64)ord_f32(v[e]) << 32) | (uint32_t)((uint32_t)(t0 * 16 + lane + 64 * e) + p.id_base);
+                cnt += __popcll(m);
+            }
+        }
+        if (qq == w) SSTAMP(11);
+        int nw;
+        if (cnt <= 64) {  // rank the survivors: lane i holds key i
+            wave_lds_fence();
+            const u64 mine = lane < cnt ? sel[lane] : KEY_PAD;
+            wave_lds_fence();
+            int rk = 0;
+            for (int j = 0; j < cnt; j++) rk += readlane_u64(mine, j) < mine ? 1 : 0;
+            if (lane < cnt && rk < k) out[rk] = mine;
+            nw = cnt < k ? cnt : k;
+        } else {
+            u64 kk[SHORT_KPL];
+#pragma unroll
+            for (int e = 0; e < SHORT_KPL; e++)
+                kk[e] = v[e] == INF ? KEY_PAD
+                                    : (((u64)ord_f32(v[e]) << 32) | (uint32_t)((uint32_t)(t0 * 16 + lane + 64 * e) + p.id_base));
+            u64 kth_unused;
+            nw = wave_select<SHORT_KPL>(kk, nkeys, k, out, &kth_unused);
+        }
+        if (lane >= nw && lane < k) out[lane] = KEY_PAD;  // k <= KB_MAX <= 64
+        if (qq == w) SSTAMP(12);
     }
-    SSTAMP(7);
+    // the ring's last R - 1 requests (issued unconditionally, past the wave's rows: a re-read of its last chunk)
+    // may still be in flight: their registers stay reserved up to here, so that the selection above does not
+    // begin by waiting for them
+#pragma unroll
+    for (int j = 0; j < R; j++)
+#pragma unroll
+        for (int s = 0; s < CH; s++) asm volatile("" ::"v"(A[j][s]));
+    SSTAMP(4);
 }
 
-template <int CH, bool BF16, bool SHIFT, bool RERANK>
-static void launch_short_one(int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortTailParams& tp) {
-    constexpr int R = CH >= 4 ? 3 : (CH == 2 ? 5 : 8);
+template <int CH, int R, int W, int WPS, bool BF16, bool SHIFT>
+static void launch_short_r(int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp) {
     static LdsAttrOnce attr;
-    attr.ensure(reinterpret_cast<const void*>(&short_scan_kernel<CH, R, BF16, SHIFT, RERANK>), LDS_LIMIT);
-    hipLaunchKernelGGL((short_scan_kernel<CH, R, BF16, SHIFT, RERANK>), dim3(grid), dim3(SHORT_W * 64), lds, st, sp, tp);
+    attr.ensure(reinterpret_cast<const void*>(&short_scan_kernel<CH, R, W, WPS, BF16, SHIFT>), LDS_LIMIT);
+    hipLaunchKernelGGL((short_scan_kernel<CH, R, W, WPS, BF16, SHIFT>), dim3(grid), dim3(W * 64), lds, st, sp, tp);
 }
-template <bool BF16, bool SHIFT, bool RERANK>
-static void launch_short_v(int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortTailParams& tp) {
-    if (ch >= 4) launch_short_one<4, BF16, SHIFT, RERANK>(grid, lds, st, sp, tp);
-    else if (ch == 2) launch_short_one<2, BF16, SHIFT, RERANK>(grid, lds, st, sp, tp);
-    else launch_short_one<1, BF16, SHIFT, RERANK>(grid, lds, st, sp, tp);
+template <int CH, int W, int WPS, bool BF16, bool SHIFT>
+static void launch_short_one(int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp) {
+    // chunks in the ring: ONE chunk (4 KB of a wave's rows at CH = 4) requested ahead of the chunk computed.
+    // Measured at 100k x 512 (profiles/r03/README.md): a deeper ring is slower here (43.9 us with one chunk
+    // ahead, 45.6 with two, per batch of 16; 36.3 against 41.4 us per step with 16 batches in flight): sixteen
+    // waves per CU keep 64 KB in flight as it is, and more requests only queue in the CU's memory pipeline
+    constexpr int R = CH >= 4 ? 2 : (CH == 2 ? 3 : 5);
+#ifdef ISE_ABLATE
+    if (SHIFT) {  // dev: ring depth A/B
+        const char* e = getenv("ISE_SHORT_RING");
+        const int r = e ? atoi(e) : 0;
+        if (r == 2) return launch_short_r<CH, 2, W, WPS, BF16, SHIFT>(grid, lds, st, sp, tp);
+        if (r == 3) return launch_short_r<CH, 3, W, WPS, BF16, SHIFT>(grid, lds, st, sp, tp);
+        if (r == 4) return launch_short_r<CH, 4, W, WPS, BF16, SHIFT>(grid, lds, st, sp, tp);
+        if (r == 6) return launch_short_r<CH, 6, W, WPS, BF16, SHIFT>(grid, lds, st, sp, tp);
+    }
+#endif
+    launch_short_r<CH, R, W, WPS, BF16, SHIFT>(grid, lds, st, sp, tp);
+}
+template <int W, int WPS, bool BF16, bool SHIFT>
+static void launch_short_ch(int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp) {
+#ifdef ISE_ABLATE
+    if (const char* e = getenv("ISE_SHORT_CH")) {  // dev: smaller chunks (must divide the row's k-steps)
+        const int c = atoi(e);
+        if ((c == 1 || c == 2) && c <= ch) ch = c;
+    }
+#endif
+    if (ch >= 4) launch_short_one<4, W, WPS, BF16, SHIFT>(grid, lds, st, sp, tp);
+    else if (ch == 2) launch_short_one<2, W, WPS, BF16, SHIFT>(grid, lds, st, sp, tp);
+    else launch_short_one<1, W, WPS, BF16, SHIFT>(grid, lds, st, sp, tp);
+}
+// block shapes: (waves, blocks per CU) = (16, 1), (8, 2), (8, 1)
+template <bool BF16, bool SHIFT>
+static void launch_short_v(int ch, int waves, int bpc, int grid, size_t lds, hipStream_t st, const ScanParams& sp,
+                           const ShortParams& tp) {
+    (void)bpc;
+    if (waves == 16) launch_short_ch<16, 4, BF16, SHIFT>(ch, grid, lds, st, sp, tp);
+    else launch_short_ch<8, 4, BF16, SHIFT>(ch, grid, lds, st, sp, tp);
 }
 
 // one launch entry point per kernel family, defined in the family's translation unit (ise_scan_*.hip)
-void ise_launch_short_f32_shift(int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortTailParams& tp);
-void ise_launch_short_f32_plain(int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortTailParams& tp);
-void ise_launch_short_bf16(int ch, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortTailParams& tp);
+void ise_launch_short_f32_shift(int ch, int waves, int bpc, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp);
+void ise_launch_short_f32_plain(int ch, int waves, int bpc, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp);
+void ise_launch_short_bf16(int ch, int waves, int bpc, int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp);

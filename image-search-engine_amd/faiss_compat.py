@@ -109,11 +109,10 @@ class IndexFlat:
         return {"combined_batches": int(out[0]), "combined_calls": int(out[1]), "direct_queries": int(out[2])}
 
     def short_stats(self) -> dict:
-        """The one-launch search of short indexes (include/ise_knn.h, ise_index_short_stats): batches it
-        answered, tail blocks that stopped waiting for the grid (expected 0)."""
-        out = (ctypes.c_uint64 * 2)()
+        """Batches scanned by the short-index kernel (include/ise_knn.h, ise_index_short_stats)."""
+        out = (ctypes.c_uint64 * 1)()
         _n.check(_n.lib.ise_index_short_stats(self._h, out))
-        return {"short_batches": int(out[0]), "gave_up": int(out[1])}
+        return {"short_batches": int(out[0])}
 
     def reserve(self, nq: int, k: int) -> None:
         """Size every internal workspace for batches of ``nq`` queries / ``k`` results now, so that the

@@ -96,12 +96,11 @@ int ise_index_get_shift(ise_index_t* h, float* mu_host);
 int ise_index_stats(ise_index_t* h, uint64_t* out4);
 
 /* Short indexes (a batch of <= 16 queries, k + spare candidates <= 32, at most 32 row tiles of 16 rows per
- * block of the grid: <= 262k rows on an MI355X) are searched by ONE launch -- scan, per-block selection, and
- * merge (+ exact re-rank) by the last blocks to arrive (csrc/ise_short_scan.hpp): the reference's own regime,
- * ~1 k images and one query per request (backend/utils.py:309-310, backend/engine.py:50-55).
- *   out2[0] batches answered that way, out2[1] tail blocks that stopped waiting for the grid (expected 0;
- *   float32 L2 queries concerned were answered by the exact scan, others came back empty).  Blocks. */
-int ise_index_short_stats(ise_index_t* h, uint64_t* out2);
+ * block of the grid: <= 262k rows on an MI355X) are scanned by short_scan_kernel (csrc/ise_short_scan.hpp: the
+ * rows' scores are dumped to LDS and selected once per block, no boot and no thresholds in the stream): the
+ * reference's own regime, ~1 k images and one query per request (backend/utils.py:309-310,
+ * backend/engine.py:50-55).  out1[0] = batches scanned that way ($ISE_NO_SHORT=1: none; same bits). */
+int ise_index_short_stats(ise_index_t* h, uint64_t* out1);
 
 /* Test / rehearsal knobs ($ISE_FORCE_EXACT, $ISE_NO_DIRECT, $ISE_NO_SHORT, $ISE_SHORT_TPB_MAX,
  * $ISE_DIRECT_MIN_TILES) are read from the environment when the library is first used and again when
