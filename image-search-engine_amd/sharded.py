@@ -161,6 +161,10 @@ class ShardedIndexFlat:
         if collective not in ("rccl", "torch"):
             raise ValueError("collective must be 'auto', 'rccl' or 'torch'")
         self.comm = None
+        # every data-path collective this rank has issued, in order: (kind, elements per rank).  All-gathers pair up
+        # across ranks by ORDER (several may be in flight on different streams over one communicator), so every
+        # rank must issue the same sequence: ``check_collective_order`` compares the logs after a run
+        self.collective_log: list = []
         if collective == "rccl":
             # every rank reports whether its communicator came up and passed the self-test; "auto"
             # then moves ALL ranks to the process group's own all-gather (still RCCL, issued by
@@ -240,6 +244,7 @@ class ShardedIndexFlat:
         else:
             keys = self.backend.local_search_keys(xq, k, self.id_base)
             gathered = torch.empty((self.world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
+        self.collective_log.append(("search", int(keys.numel())))
         if self.comm is not None:  # stream-ordered behind the scan, nothing to wait for on the host
             self.comm.all_gather_into(gathered.view(-1), keys.view(-1),
                                       torch.cuda.current_stream(keys.device).cuda_stream)
@@ -259,6 +264,29 @@ class ShardedIndexFlat:
     def search(self, xq: torch.Tensor, k: int):
         """(D, I) identical on every rank and identical to an unsharded IndexFlat."""
         return self.search_end(self.search_begin(xq, k))
+
+    def check_collective_order(self) -> dict:
+        """Collective (call it on every rank, outside any timed region, with nothing in flight): every rank's
+        log of issued all-gathers must be the same sequence -- the invariant the exchange relies on.  Returns
+        ``{"collectives": n, "ranks_agree": True}`` or raises ``RuntimeError`` naming the first difference.
+        The comparison itself goes through ``torch.distributed`` (one all-gather of a digest), never through
+        the communicator under test."""
+        import hashlib
+
+        blob = repr(self.collective_log).encode()
+        mine = torch.tensor([len(self.collective_log)] + list(hashlib.sha256(blob).digest()[:15]), dtype=torch.int64)
+        dev = getattr(self.backend, "device", torch.device("cpu"))
+        on_gpu = dev.type == "cuda" and dist.get_backend(self.group) == "nccl"
+        if on_gpu:
+            mine = mine.to(dev)
+        allv = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(allv, mine, group=self.group)
+        rows = allv.view(self.world, -1).cpu().tolist()
+        for r, row in enumerate(rows):
+            if row != rows[0]:
+                raise RuntimeError(f"collective order differs between rank 0 ({rows[0][0]} collectives) and rank {r} "
+                                   f"({row[0]} collectives); this rank's last entries: {self.collective_log[-4:]}")
+        return {"collectives": len(self.collective_log), "ranks_agree": True}
 
 
 class SearchPipeline:
@@ -353,6 +381,7 @@ class SearchPipeline:
             g3 = gathered.view(world, m * self.nq, self.k)
             D, I = b["D"][: m * self.nq], b["I"][: m * self.nq]
         be = self.index.backend
+        self.index.collective_log.append(("bucket", self.cur, m, int(keys.numel())))
         if self.cuda and getattr(self.index, "comm", None) is not None:  # one C call: ncclAllGather on the bucket's stream
             self.index.comm.all_gather_into(gathered, keys, b["handle"])
             be.merge_into(g3, D, I, b["handle"])

@@ -108,6 +108,22 @@ def _worker(rank, world, port, metric, n, q, storage="f32"):
         assert pipe.flush() == []
         with pytest.raises(ValueError):
             pipe.submit(tq[:1])
+        # the invariant the exchange relies on: every rank issued the same sequence of all-gathers
+        # (3 one-batch searches + 3 buckets, the last one partial)
+        rep = idx.check_collective_order()
+        assert rep == {"collectives": 6, "ranks_agree": True}, rep
+        assert idx.collective_log[3:] == [("bucket", 0, 3, 3 * nqp * k), ("bucket", 1, 3, 3 * nqp * k),
+                                          ("bucket", 0, 2, 2 * nqp * k)], idx.collective_log
+        if world > 1:
+            if rank == 1:   # a rank that issued one more is found out (the check is collective: every rank runs it)
+                idx.collective_log.append(("search", 1))
+            try:
+                idx.check_collective_order()
+                raise AssertionError("a diverging collective log went unnoticed")
+            except RuntimeError as e:
+                assert "collective order differs" in str(e)
+            if rank == 1:
+                idx.collective_log.pop()
         # every rank holds the same answer
         allI = [torch.empty_like(I) for _ in range(world)]
         dist.all_gather(allI, I)
