@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512, 2) void assign_kernel(const AssignParams p) {
     const int CS = p.cs;
     float* cs = reinterpret_cast<float*>(smem);  // [CS][S]
     float* cn = cs + CS * S;                     // [CS]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar
     const int c = lane & 15, g = lane >> 4;
     const bool l2 = p.metric == ISE_METRIC_L2;
     const long long rows_per_block = (long long)W * XT * 16;

@@ -147,7 +147,7 @@ __device__ __forceinline__ void rerank_block(const ExactParams& p, int q, unsign
     float* qs = reinterpret_cast<float*>(smem);
     u64* kin = reinterpret_cast<u64*>(qs + p.dp);
     u64* kex = kin + p.kc;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar
     const int n2 = rerank_pow2(p.kc);
     DBG_STAMP(p.stats ? p.stats + 8 : nullptr, 3);
     if (keys_in_global)

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, QN == 1 ? 2 : 4) void exact_scan_kernel(const 
     extern __shared__ __align__(16) unsigned char smem_xs[];
     float* qs = reinterpret_cast<float*>(smem_xs);            // [QN][dp]
     u64* wl = reinterpret_cast<u64*>(qs + (size_t)QN * p.dp);  // [QN][4 waves][32]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar
     const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
     const long long r_end = min(p.n, r_begin + p.rows_per_block);
     const int kp = p.kpass;

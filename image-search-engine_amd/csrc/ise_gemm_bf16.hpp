@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
     float* qbuf1 = qbuf0 + (size_t)GB_GQ * S;
     float* tauL = qbuf1 + (size_t)GB_GQ * S;           // [GEMM_NQ_MAX]
     float* xnL = tauL + GEMM_NQ_MAX;                   // [GEMM_NQ_MAX]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar
     const int c = lane & 15, g = lane >> 4;
     const int nstages = p.nq_pad / GB_GQ;
     constexpr bool l2 = L2;

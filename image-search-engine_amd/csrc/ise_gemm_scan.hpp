@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict
     __shared__ u64 topk[64];
     __shared__ int cnt;
     __shared__ u64 ubound;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (q >= nq) {  // padding queries admit nothing
         if (tid == 0) tau[q] = -FLT_MAX;
         return;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
     float* tauL = qbuf1 + (size_t)GQ * S;             // [GEMM_NQ_MAX]
     float* xnL = tauL + GEMM_NQ_MAX;                  // [GEMM_NQ_MAX]
     float* muL = xnL + GEMM_NQ_MAX;                   // [S]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar
     const int c = lane & 15, g = lane >> 4;
     const int nstages = p.nq_pad / GQ;
 

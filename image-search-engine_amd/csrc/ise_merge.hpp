@@ -82,7 +82,7 @@ struct ListHeads {
 // (any k).  emit(r, key) is called by exactly one thread per round (tid 0 for the KEY_PAD tail).
 template <int NT, int LPT, typename Emit>
 __device__ __forceinline__ void merge_rounds(const MergeParams& p, const u64* base, u64 (*wmin)[NT / 64], Emit emit) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar
     const int k = p.k;
     ListHeads<NT, LPT> h;
     h.load(p, base);
@@ -120,7 +120,7 @@ struct MergeFastScratch {
 };
 __device__ __forceinline__ void merge_waves(const MergeParams& p, const u64* base, MergeFastScratch& s, u64* out) {
     constexpr int NW = MERGE_THREADS / 64, LPT = MERGE_LISTS_MAX / MERGE_THREADS;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar
     const int k = p.k;
     ListHeads<MERGE_THREADS, LPT> h;
     h.load(p, base);

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     u64* cand = bootw + NQ * kb;                                // [W][NQ][CAP]
     u64* boot = cand;                                           // [NQ][W*16], dead before cand is used
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar
     const int c = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.y * NQ;
     const int nqt = min(NQ, p.nq - q0);  // valid queries of this pass
