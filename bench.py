@@ -54,7 +54,7 @@ def host_cores():
     return n
 
 
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 CLOCK_WARMUP_STEPS = 400  # untimed, before the W warm-up steps: see main()
 
 
@@ -77,17 +77,34 @@ def kernel_source_hash():
 
 def pmc_traffic(n, d, nq, k, world):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/<round>/bench_nq<nq>_hbm_pmc.json; counters cannot be read from inside the timed
+    (profiles/<round>/bench_n<n>_nq<nq>_hbm_pmc.json; counters cannot be read from inside the timed
     process).  The capture names the kernel sources it was taken on: if they have changed since,
     the figure is stale and None is reported instead."""
-    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"bench_nq{nq}_hbm_pmc.json")
-    if world != 1 or (n, d, k) != (1_000_000, 512, 10) or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"bench_n{n}_nq{nq}_hbm_pmc.json")
+    if world != 1 or (d, k) != (512, 10) or not os.path.exists(path):
         return None
     with open(path) as f:
         rec = json.load(f)
     if rec.get("kernel_source_hash") != kernel_source_hash():
         return None
     return rec["scan_kernel"]["traffic_bytes_per_launch"]
+
+
+def committed_overlap(n, d, nq, k, world):
+    """How the scan kernels of consecutive steps overlap on the GPU in THIS command's timed configuration
+    (16 issue streams): reduced from a `rocprofv3 --kernel-trace` of the same command by
+    scripts/overlap_from_trace.py and committed under profiles/<round>/ (a process cannot trace itself).
+    Tied to the kernel sources like the counter capture: stale captures are not reported."""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"bench_n{n}_nq{nq}_streams16_overlap.json")
+    if world != 1 or d != 512 or k != 10 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    keep = ("kernel", "launches", "mean_duration_us", "std_duration_us", "mean_start_to_start_us",
+            "fraction_of_time_with_n_of_this_kernel_resident", "mean_kernels_resident", "hardware_queues")
+    return {key: rec[key] for key in keep if key in rec}
 
 
 class BoardPower:
@@ -317,6 +334,15 @@ def main():
     # batches of >= 256 queries take the GEMM-shaped pass (csrc/ise_gemm_scan.hpp): MFMA-bound, priced in flops
     gemm_batch = local.exact_stats().get("gemm_chunks", 0) > 0
     alg_flops = 2.0 * nq * n_local * d
+    # which kernel scanned the rows (the dominant kernel of the step)
+    if gemm_batch:
+        kernel_name = "gemm_scan_kernel (threshold sample + main pass)"
+    elif local.host_stats()["direct_queries"] > 0:
+        kernel_name = "exact_scan_kernel<1, nt> (one-query batches: the direct-difference scan is the whole search)"
+    elif local.short_stats()["short_batches"] > 0:
+        kernel_name = "short_scan_kernel (short index: scores dumped to LDS, one selection per block)"
+    else:
+        kernel_name = "scan_kernel"
 
     # per-batch latency (median + p10/p90): one batch at a time on one stream, an
     # event pair around scan + merge.  Single-GPU runs only; the timed region above is the metric.
@@ -342,6 +368,26 @@ def main():
             run(200)
             torch.cuda.synchronize()
         board_power = power.stop(t_seg + 1.2)
+
+    # N > 1: what a SCALE record needs to describe itself -- every rank's own shard roofline, the collective in
+    # use and the ranks it reached, and the check that all ranks issued the same sequence of all-gathers.
+    # Then the communicator and the process group go away BEFORE rank 0 regenerates the index and runs the
+    # CPU oracle pass (15-20 s): the other ranks are not parked in a barrier meanwhile.
+    multi = None
+    D_host, I_host = D.cpu(), I.cpu()
+    if sharded:
+        mine = {"rank": rank, "rows": n_local, "kernel_ms": scan_ms, "achieved_gbs": achieved,
+                "frac": achieved / HBM_PEAK_GBS}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        order = index.check_collective_order()   # raises on every rank if the sequences differ
+        multi = {"per_rank_roofline": per_rank, "collective": index.collective, "ranks_seen": index.ranks_seen,
+                 "collective_order": order}
+        if index.comm is not None:  # the library's communicator goes before the process group that bootstrapped it
+            torch.cuda.synchronize()
+            barrier()
+            index.comm.close()
+        dist.destroy_process_group()
 
     if rank == 0:
         res = {
@@ -372,7 +418,8 @@ def main():
                          "frac": (alg_flops / (scan_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF) if gemm_batch
                          else achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n, d, nq, k, world),
-                         "kernel": "gemm_scan_kernel (threshold sample + main pass)" if gemm_batch else "scan_kernel",
+                         "kernel": kernel_name,
+                         "kernel_overlap": committed_overlap(n, d, nq, k, world),
                          "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms, "board_power": board_power,
                          "algorithmic_bytes": alg_bytes, "algorithmic_flops": alg_flops,
                          # the same bytes over the measured step time (batches overlapped on the GPU):
@@ -382,10 +429,12 @@ def main():
                          "kernel_ms_source": "50 back-to-back launches on one stream, HIP events around the kernel "
                                              "(ise_index_search_timed_device); merge_kernel_ms = everything behind "
                                              "the scan (merge + exact re-rank + the gated exact-scan launches); "
-                                             f"rocprofv3 agreement: profiles/{PROFILE_ROUND}/bench_nq16_streams1_kernel_stats.csv"},
+                                             f"rocprofv3 agreement: profiles/{PROFILE_ROUND}/ (kernel_stats CSVs, README.md)"},
         }
         if latency is not None:
             res["batch_latency_us"] = latency
+        if multi is not None:
+            res["multi_gpu"] = multi
         if not args.no_cpu_baseline:
             from oracle import flat_oracle as fo
 
@@ -400,7 +449,7 @@ def main():
             # parity gate on the benchmark data itself, at every N: full-index CPU pass (oracle) for the
             # batch the last timed step answered
             Dc, Ic, _ = fo.knn_flat(xb_full, xq_host, k, 1, cores)
-            In, Dn = I.cpu().numpy(), D.cpu().numpy()
+            In, Dn = I_host.numpy(), D_host.numpy()
             res["recall_at_k"] = float(np.mean([len(set(In[q]) & set(Ic[q])) / k for q in range(nq)]))
             res["ids_identical"] = bool(np.array_equal(In, Ic))
             res["max_abs_dist_err"] = float(np.abs(Dn - Dc).max())
@@ -421,12 +470,6 @@ def main():
             res["config"]["workload"] += " [rehearsal: sharded code path in a world of one]"
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
-    if sharded:
-        if index.comm is not None:  # the library's communicator goes before the process group that bootstrapped it
-            torch.cuda.synchronize()
-            barrier()
-            index.comm.close()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -108,9 +108,9 @@ class RcclComm:
         self._h = ctypes.c_void_p()
         _n.check(_n.lib.ise_comm_create(ctypes.byref(self._h), raw, world, rank, device.index))
 
-    def self_test(self, group) -> None:
+    def self_test(self, group) -> list:
         """One tiny all-gather checked on the host (every rank sends its own rank): a communicator that
-        cannot reach its peers shows here, at start-up, not as a wrong merge later."""
+        cannot reach its peers shows here, at start-up, not as a wrong merge later.  Returns the ranks seen."""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         send = torch.full((4,), rank, dtype=torch.int64, device=self.device)
         recv = torch.full((4 * world,), -1, dtype=torch.int64, device=self.device)
@@ -120,6 +120,7 @@ class RcclComm:
         want = torch.arange(world, dtype=torch.int64).repeat_interleave(4)
         if not torch.equal(recv.cpu(), want):
             raise RuntimeError(f"RCCL self-test: rank {rank} gathered {recv.cpu().tolist()}")
+        return recv.cpu()[::4].tolist()
 
     def all_gather_into(self, gathered: torch.Tensor, keys: torch.Tensor, stream: int) -> None:
         """gathered (world * n int64, contiguous) <- every rank's keys (n int64), on ``stream``."""
@@ -161,6 +162,7 @@ class ShardedIndexFlat:
         if collective not in ("rccl", "torch"):
             raise ValueError("collective must be 'auto', 'rccl' or 'torch'")
         self.comm = None
+        self.ranks_seen = None  # ranks the library's communicator reached in its start-up self-test (collective "rccl")
         # every data-path collective this rank has issued, in order: (kind, elements per rank).  All-gathers pair up
         # across ranks by ORDER (several may be in flight on different streams over one communicator), so every
         # rank must issue the same sequence: ``check_collective_order`` compares the logs after a run
@@ -172,7 +174,7 @@ class ShardedIndexFlat:
             err = None
             try:
                 self.comm = RcclComm(group, dev)
-                self.comm.self_test(group)
+                self.ranks_seen = self.comm.self_test(group)
             except Exception as e:  # noqa: BLE001 -- reported below, on every rank
                 err = e
             ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)

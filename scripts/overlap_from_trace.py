@@ -13,7 +13,11 @@ import json
 import sys
 from collections import defaultdict
 
+import os
+
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
@@ -72,6 +76,12 @@ def main():
         "hardware_queues": sorted({q for _, _, q in sel}),
         "other_kernels_in_window": {n[:80]: {"calls": len(v), "mean_us": float(np.mean(v) / 1e3)} for n, v in others.items()},
     }
+    try:  # tie the record to the kernel sources it was taken on (bench.py drops stale records)
+        from bench import kernel_source_hash
+
+        out["kernel_source_hash"] = kernel_source_hash()
+    except Exception:  # noqa: BLE001
+        pass
     txt = json.dumps(out, indent=1)
     print(txt)
     if a.json:
