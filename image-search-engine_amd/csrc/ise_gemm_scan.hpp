@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q,
     float s = 0.f;
     for (int j = lane; j < S; j += 64) {
         float v = 0.f;
-        if (i < nq && j < d) v = q[(size_t)i * d + j] - mu[j];
+        if (i < nq && j < d) v = q[(size_t)i * d + j] - (mu ? mu[j] : 0.f);  // mu = null: inner product, no shift
         qprep[(size_t)i * S + j] = v;
         s = fmaf(v, v, s);
     }
@@ -140,7 +140,11 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict
     if (tid == 0) tau[q] = unord_f32((uint32_t)(lst[kc - 1] >> 32));  // n >= kc: the kc minima below U are in the list
 }
 
-template <int NS, bool DUMP>
+// IPM: float32 INNER PRODUCT rows (the reference's default "cosine" index, backend/utils.py:293,300-303): no
+// shift, no norms, the score is -x.y summed exactly as scan_kernel sums it (elements 0, 2 of every k-step in
+// one accumulator chain, 1, 3 in the other, then their sum), so that the large-batch path returns the bits of
+// the streaming passes; no re-rank behind it (gemm_select_plain_kernel emits the k best candidates).
+template <int NS, bool DUMP, bool IPM = false>
 __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams p) {
     extern __shared__ __align__(16) unsigned char smem_g[];
     const int S = p.S;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
         tauL[i] = DUMP ? 0.f : fminf(p.tau[i], 3.4028233e38f);
         xnL[i] = p.xn[i];
     }
-    for (int i = tid; i < S; i += 512) muL[i] = i < p.dp ? p.mu[i] : 0.f;
+    for (int i = tid; i < S; i += 512) muL[i] = (!IPM && i < p.dp) ? p.mu[i] : 0.f;
     stage_load(st0, qbuf0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -189,11 +193,13 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
         {
             const float* rp = p.xb + (size_t)rr * p.dp + 4 * g;
 #pragma unroll
-            for (int s = 0; s < NS; s++)
-                a[s] = *reinterpret_cast<const f32x4*>(rp + 16 * s) - *reinterpret_cast<const f32x4*>(muL + 16 * s + 4 * g);
+            for (int s = 0; s < NS; s++) {
+                a[s] = *reinterpret_cast<const f32x4*>(rp + 16 * s);
+                if (!IPM) a[s] = a[s] - *reinterpret_cast<const f32x4*>(muL + 16 * s + 4 * g);
+            }
         }
         f32x4 yn = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (row_base + 4 * g + 3 < p.rows16) yn = *reinterpret_cast<const f32x4*>(p.norms + row_base + 4 * g);
+        if (!IPM && row_base + 4 * g + 3 < p.rows16) yn = *reinterpret_cast<const f32x4*>(p.norms + row_base + 4 * g);
         const long long left = p.n - (row_base + 4 * g);
         const int nv = left >= 4 ? 4 : (left > 0 ? (int)left : 0);  // valid rows among this lane's four: checked once per slab
 
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
             const float* q0 = cur + (size_t)c * S + 4 * g;
             const float* q1 = q0 + (size_t)16 * S;
             f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 odd0 = (f32x4){0.f, 0.f, 0.f, 0.f}, odd1 = (f32x4){0.f, 0.f, 0.f, 0.f};  // IPM: the chains of elements 1, 3
             f32x4 b0 = *reinterpret_cast<const f32x4*>(q0), b1 = *reinterpret_cast<const f32x4*>(q1);
 #pragma unroll
             for (int s = 0; s < NS; s++) {
@@ -214,6 +221,16 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
                     nb1 = *reinterpret_cast<const f32x4*>(q1 + 16 * (s + 1));
                 }
                 // two independent accumulator chains, interleaved: the 40-cycle dependent latency never shows
+                if constexpr (IPM) {  // scan_kernel's summation order: four chains, none waits for another
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], b0[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], b1[0], acc1, 0, 0, 0);
+                    odd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], b0[1], odd0, 0, 0, 0);
+                    odd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], b1[1], odd1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], b0[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], b1[2], acc1, 0, 0, 0);
+                    odd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], b0[3], odd0, 0, 0, 0);
+                    odd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], b1[3], odd1, 0, 0, 0);
+                } else {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], b0[0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], b1[0], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], b0[1], acc0, 0, 0, 0);
@@ -222,6 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][2], b1[2], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], b0[3], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][3], b1[3], acc1, 0, 0, 0);
+                }
                 b0 = nb0;
                 b1 = nb1;
                 __builtin_amdgcn_sched_barrier(0);  // B fragments are requested one k-step ahead, not all up front (registers)
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
             // ---- epilogue: lane (c, g) holds rows 4g..4g+3 of its tile against query c of either query tile
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                const f32x4 dot = t ? acc1 : acc0;
+                const f32x4 dot = IPM ? (t ? acc1 + odd1 : acc0 + odd0) : (t ? acc1 : acc0);
                 const int q = sq * GQ + t * 16 + c;
                 const float xq_n = xnL[q], tq = tauL[q];
                 float lo[4];
@@ -238,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_kernel(const GemmScanParams 
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float tt = xq_n + yn[j];
-                    lo[j] = fmaf(-p.beta, tt, tt - 2.f * dot[j]);
+                    lo[j] = IPM ? -dot[j] : fmaf(-p.beta, tt, tt - 2.f * dot[j]);
                     pass[j] = lo[j] <= tq && j < nv;
                     any |= pass[j];
                 }

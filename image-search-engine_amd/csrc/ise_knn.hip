@@ -169,7 +169,9 @@ static int qs_stride_for(const ise_index* h) {
     const int pad = ((2 - (units / 4)) % 16 + 16) % 16 * 4;
     return units + pad;
 }
-#define KPASS_MAX 32 /* largest k one scan pass selects; larger k runs floor-keyed passes */
+#define KPASS_MAX 36 /* most keys per query one scan pass selects: k = 32 with the exact path's 4 spare candidates still is
+                        ONE pass (k = 29..32 took two: 730 us instead of 355 at 1M x 512); more: floor-keyed passes */
+#define XPASS_MAX 32 /* most results per query of one exact-scan pass, of the direct scan and of the large-batch paths */
 static size_t scan_lds_bytes(const ise_index* h, int waves, int T, int kb) {
     return scan_lds_layout(qs_stride_for(h), waves, T, kb);
 }
@@ -611,7 +613,7 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
     pl->exact = uses_shift(h);
     pl->kc = pl->exact ? k + exact_extra(k) : k;
     pl->kpass = pl->kc < KPASS_MAX ? pl->kc : KPASS_MAX;
-    pl->kb = pl->kpass <= 16 ? 16 : 32;
+    pl->kb = pl->kpass <= 16 ? 16 : (pl->kpass <= 32 ? 32 : KB_MAX);
     pl->ch = chunk_steps(h);
 #ifdef ISE_ABLATE
     if (const char* e = getenv("ISE_CH")) {  // dev: force a smaller chunk (must divide dp/16)
@@ -754,7 +756,7 @@ static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long lon
         *changed = true;
     }
     if (pl.kc > pl.kpass) {
-        const size_t need2 = (size_t)nq * ((size_t)pl.kc + 2 + pl.kpass + KPASS_MAX);
+        const size_t need2 = (size_t)nq * ((size_t)pl.kc + 2 + pl.kpass + XPASS_MAX);
         if (need2 > w->keys_tmp_elems) {
             if (w->keys_tmp) (void)hipFree(w->keys_tmp);
             w->keys_tmp = nullptr;
@@ -879,7 +881,7 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
     mp.lists = w->part; mp.qt = 1; mp.n_lists = pl.nblocks; mp.nq = (int)nq; mp.metric = h->metric;
     mp.fl_state = w->fl_state; mp.fl_list = w->fl_list; mp.seq = xp.seq; mp.dbg = nullptr; mp.gate = nullptr;
     const int k = xp.k;
-    if (k <= KPASS_MAX) {
+    if (k <= XPASS_MAX) {
         xs.kpass = k; xs.floor_keys = nullptr;
         mp.k = k; mp.stride_list = k; mp.stride_qtile = (long long)pl.nblocks * k;
         mp.D = xp.D; mp.I = xp.I; mp.keys_out = xp.keys_out; mp.out_by_pos = 0;
@@ -888,8 +890,8 @@ static int enqueue_exact_fallback(ise_index* h, ise_index::WorkSlot* w, const Sc
         return ISE_OK;
     }
     u64* fb_floor = w->keys_tmp + (size_t)nq * ((size_t)pl.kc + 1 + pl.kpass);  // [nq]
-    u64* fb_pass = fb_floor + nq;                                             // [nq][KPASS_MAX]
-    const int kp = KPASS_MAX;
+    u64* fb_pass = fb_floor + nq;                                             // [nq][XPASS_MAX]
+    const int kp = XPASS_MAX;
     for (int off = 0; off < k; off += kp) {
         xs.kpass = kp; xs.floor_keys = off ? fb_floor : nullptr;
         mp.k = kp; mp.stride_list = kp; mp.stride_qtile = (long long)pl.nblocks * kp;
@@ -914,7 +916,7 @@ static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, con
                            int* blocks_out) {
     // one query only: two to four queries are VALU-bound here (380-520 us) and faster through the filter (356 us)
     // (ISE_FORCE_EXACT asks for the filtered path's fallback to be exercised: it implies the filtered path)
-    if (!pl.exact || nq != 1 || k > KPASS_MAX || h->n <= 0 || !w->fl_state || no_direct() || force_exact()) return false;
+    if (!pl.exact || nq != 1 || k > XPASS_MAX || h->n <= 0 || !w->fl_state || no_direct() || force_exact()) return false;
     // short indexes: the filtered search behind the short-index kernel (ise_short_scan.hpp) is faster than this
     // scan's serial tail (100k x 512: 56.9 us per step direct); $ISE_DIRECT_MIN_TILES moves the crossover
     const int min_tiles = knobs().direct_min_tiles.load(std::memory_order_relaxed);
@@ -969,9 +971,9 @@ static bool gemm_applies(const ise_index* h, long long nq, int k) {
     const long long need = h->storage == ISE_STORE_BF16 ? std::min<long long>(min_nq, 128) : min_nq;
     if (off || nq < need || h->n < 128ll * 1024) return false;  // shorter indexes: the streaming passes are as fast
     if (h->dp > 512 || h->dp % 128 != 0) return false;            // the row tiles live in <= 128 VGPRs
-    if (h->storage == ISE_STORE_BF16) return k <= KPASS_MAX;      // either metric (ise_gemm_bf16.hpp)
-    if (!uses_shift(h)) return false;                             // float32 inner product: the streaming passes
-    return k + exact_extra(k) <= KPASS_MAX;                       // the select stage hands one pass of candidates to the re-rank
+    if (h->storage == ISE_STORE_BF16) return k <= XPASS_MAX;      // either metric (ise_gemm_bf16.hpp)
+    if (!uses_shift(h)) return k <= XPASS_MAX;                    // float32 inner product: no re-rank behind the pass
+    return k + exact_extra(k) <= XPASS_MAX;                       // the select stage hands at most 32 candidates to the re-rank
 }
 #define GEMM_CAPW 2048 /* entries of a wave's candidate buffer (expected fill: a few hundred) */
 struct GemmLayout {
@@ -1004,11 +1006,16 @@ static int plan_for_batch(const ise_index* h, long long nq, int k, ScanPlan* pl)
     return ISE_OK;
 }
 
+template <int NS, bool DUMP, bool IPM>
+static void launch_gemm_metric(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
+    static LdsAttrOnce attr;
+    attr.ensure(reinterpret_cast<const void*>(&gemm_scan_kernel<NS, DUMP, IPM>), LDS_LIMIT);
+    hipLaunchKernelGGL((gemm_scan_kernel<NS, DUMP, IPM>), dim3(grid), dim3(512), lds, st, gp);
+}
 template <int NS, bool DUMP>
 static void launch_gemm_one(int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
-    static LdsAttrOnce attr;
-    attr.ensure(reinterpret_cast<const void*>(&gemm_scan_kernel<NS, DUMP>), LDS_LIMIT);
-    hipLaunchKernelGGL((gemm_scan_kernel<NS, DUMP>), dim3(grid), dim3(512), lds, st, gp);
+    if (gp.metric == ISE_METRIC_INNER_PRODUCT) launch_gemm_metric<NS, DUMP, true>(grid, lds, st, gp);
+    else launch_gemm_metric<NS, DUMP, false>(grid, lds, st, gp);
 }
 template <bool DUMP>
 static int launch_gemm(int ns, int grid, size_t lds, hipStream_t st, const GemmScanParams& gp) {
@@ -1047,7 +1054,7 @@ static int search_large_chunk(ise_index* h, ise_index::WorkSlot* w, const float*
     GemmScanParams gp;
     gp.xb = (const float*)h->xb; gp.norms = h->norms; gp.mu = h->mu; gp.n = h->n; gp.rows16 = (h->n + 15) / 16 * 16;
     gp.dp = h->dp; gp.S = S; gp.qprep = qprep; gp.xn = xn; gp.tau = tau; gp.nq = (int)nq; gp.nq_pad = nq_pad;
-    gp.beta = exact_beta(h); gp.id_base = id_base;
+    gp.beta = exact_beta(h); gp.id_base = id_base; gp.metric = ISE_METRIC_L2;
     gp.wbuf = reinterpret_cast<u32x4*>(w->gemm + gl.wbuf); gp.wcnt = reinterpret_cast<unsigned int*>(w->gemm + gl.wcnt);
     gp.capw = GEMM_CAPW;
     gp.ablate = 0;
@@ -1318,6 +1325,75 @@ static int search_large_chunk_bf16(ise_index* h, ise_index::WorkSlot* w, const f
     return ISE_OK;
 }
 
+// float32 INNER PRODUCT rows, one chunk of <= GEMM_NQ_MAX queries: the GEMM-shaped pass of ise_gemm_scan.hpp without
+// shift, norms or re-rank (the reference's default index type is "cosine" = IndexFlatIP over normalised rows,
+// backend/utils.py:293,300-303): sample dump -> thresholds (the k-th smallest sampled score) -> GEMM pass ->
+// regroup -> select; then the streaming passes, gated on the rerun flag (set when a candidate buffer overflowed).
+// Same bits as the streaming passes: the kernel sums a dot product in scan_kernel's order.
+static int search_large_chunk_ip(ise_index* h, ise_index::WorkSlot* w, const float* q_dev, long long nq, int k,
+                                 uint32_t id_base, float* D_dev, long long* I_dev, u64* keys_out, hipStream_t st,
+                                 TimedOut* tm) {
+    const int S = qs_stride_for(h);
+    const GemmLayout gl = gemm_layout(h);
+    h->gemm_chunks++;
+    float* qprep = reinterpret_cast<float*>(w->gemm + gl.qprep);
+    float* xn = reinterpret_cast<float*>(w->gemm + gl.xn);
+    float* tau = reinterpret_cast<float*>(w->gemm + gl.tau);
+    unsigned int* ccnt = reinterpret_cast<unsigned int*>(w->gemm + gl.ccnt);
+    float* dump = reinterpret_cast<float*>(w->gemm + gl.dump);
+    u64* cand = reinterpret_cast<u64*>(w->gemm + gl.cand);
+    const int nq_pad = (int)((nq + GQ - 1) / GQ * GQ);
+    int rc;
+
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
+    hipLaunchKernelGGL(qprep_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, q_dev, (int)nq, nq_pad, h->d, S,
+                       (const float*)nullptr, qprep, xn);
+    HIP_TRY(hipGetLastError());
+
+    GemmScanParams gp;
+    gp.xb = (const float*)h->xb; gp.norms = h->norms; gp.mu = nullptr; gp.n = h->n; gp.rows16 = (h->n + 15) / 16 * 16;
+    gp.dp = h->dp; gp.S = S; gp.qprep = qprep; gp.xn = xn; gp.tau = tau; gp.nq = (int)nq; gp.nq_pad = nq_pad;
+    gp.beta = 0.f; gp.id_base = id_base; gp.metric = ISE_METRIC_INNER_PRODUCT;
+    gp.wbuf = reinterpret_cast<u32x4*>(w->gemm + gl.wbuf); gp.wcnt = reinterpret_cast<unsigned int*>(w->gemm + gl.wcnt);
+    gp.capw = GEMM_CAPW;
+    gp.ablate = 0;
+    const int slabs_all = (int)((h->n + 127) / 128);
+    const size_t lds = gemm_lds_bytes(S);
+    const int ns = h->dp / 16;
+
+    gp.slabs = std::min(slabs_all, GEMM_SAMPLE_SLABS);
+    gp.slab_stride = slabs_all / gp.slabs;
+    const int nstages = nq_pad / GQ;
+    gp.qparts = std::max(1, std::min(nstages, (2 * h->num_cu) / gp.slabs));
+    gp.dump = dump;
+    if ((rc = launch_gemm<true>(ns, gp.slabs * gp.qparts, lds, st, gp))) return rc;
+    hipLaunchKernelGGL(kth_select_kernel, dim3((unsigned)nq_pad), dim3(256), 0, st, (const float*)dump, gp.slabs * 128, k,
+                       (int)nq, tau);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(GEMM_NQ_MAX * GEMM_SUBS + 64) * 4, st));  // counters, overflow flag, rerun flag
+
+    gp.slabs = slabs_all; gp.slab_stride = 1; gp.qparts = 1; gp.dump = nullptr;
+    const int grid = std::min(slabs_all, h->num_cu);
+    if ((rc = launch_gemm<false>(ns, grid, lds, st, gp))) return rc;
+    unsigned int* overflow = ccnt + GEMM_NQ_MAX * GEMM_SUBS;
+    unsigned int* rerun = overflow + 1;
+    hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)grid * 8), dim3(256), 0, st, (const u32x4*)gp.wbuf,
+                       (const unsigned int*)gp.wcnt, GEMM_CAPW, cand, ccnt, GEMM_CAPQ, overflow);
+    HIP_TRY(hipGetLastError());
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
+    hipLaunchKernelGGL(gemm_select_plain_kernel, dim3((unsigned)nq), dim3(256), (size_t)GEMM_CAPQ * 8, st, (const u64*)cand,
+                       (const unsigned int*)ccnt, GEMM_CAPQ, (const unsigned int*)overflow, rerun, k, h->metric, D_dev, I_dev,
+                       keys_out);
+    HIP_TRY(hipGetLastError());
+    ScanPlan pl;
+    rc = make_plan(h, nq, k, &pl, /*allow_short=*/false);  // a gated rerun: the streaming kernels carry the gate
+    if (rc) return rc;
+    rc = scan_path_enqueue(h, w, pl, q_dev, nq, k, id_base, D_dev, I_dev, keys_out, st, nullptr, rerun);
+    if (rc) return rc;
+    if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e2, st));
+    return ISE_OK;
+}
+
 // enqueue one search batch; outputs (D, I) and/or keys.  Nothing here blocks once the slots are
 // sized (first batch of a shape) and the shift is current (first batch after rows were added).
 static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k, uint32_t id_base, float* D_dev,
@@ -1349,7 +1425,9 @@ static int search_enqueue(ise_index* h, const float* q_dev, long long nq, int k,
     if (pl.gemm) {  // float32 L2 or bf16 rows, nq >= 256: GEMM-shaped pass, GEMM_NQ_MAX queries at a time
         for (long long q0 = 0; q0 < nq; q0 += GEMM_NQ_MAX) {
             const long long m = std::min<long long>(GEMM_NQ_MAX, nq - q0);
-            rc = (h->storage == ISE_STORE_BF16 ? search_large_chunk_bf16 : search_large_chunk)(
+            rc = (h->storage == ISE_STORE_BF16 ? search_large_chunk_bf16
+                  : uses_shift(h)               ? search_large_chunk
+                                                : search_large_chunk_ip)(
                 h, w, q_dev + (size_t)q0 * h->d, m, k, id_base, D_dev ? D_dev + (size_t)q0 * k : nullptr,
                 I_dev ? I_dev + (size_t)q0 * k : nullptr, keys_out ? keys_out + (size_t)q0 * k : nullptr, st, tm);
             if (rc) return rc;
@@ -1454,7 +1532,7 @@ static int search_host_direct(ise_index* h, const float* q, long long nq, int k,
     struct Rel { ise_index* h; ise_index::HostCtx* c; ~Rel() { release_ctx(h, c); } } rel{h, c};
     if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // bounds the workspace (part + multi-pass keys); larger calls loop
-    const long long batch = k + 6 <= KPASS_MAX ? 4096 : 1024;
+    const long long batch = k + 6 <= XPASS_MAX ? 4096 : 1024;
     const size_t qe = (size_t)std::min<long long>(nq, batch) * h->d;
     const size_t oe = (size_t)std::min<long long>(nq, batch) * k;
     if (qe > c->q_elems) {
@@ -1571,7 +1649,7 @@ extern "C" int ise_index_search_host(ise_index_t* h, const float* q, int64_t nq,
     if (!D || !I) return fail(ISE_E_INVALID, "output pointer is NULL");
     const long long cmax = host_combine_max();
     // large calls fill their own passes; a large k costs the others more than the shared pass saves
-    if (nq > 16 || nq > cmax || k > KB_MAX) return search_host_direct(h, q, nq, k, D, (long long*)I);
+    if (nq > 16 || nq > cmax || k > XPASS_MAX) return search_host_direct(h, q, nq, k, D, (long long*)I);
 
     ise_index::HostReq r;
     r.q = q; r.nq = nq; r.k = k; r.D = D; r.I = (long long*)I;

@@ -111,7 +111,7 @@ __device__ __forceinline__ void merge_rounds(const MergeParams& p, const u64* ba
 //      (about 2 each) and every wave is done; otherwise -- rare -- all waves go on to k rounds and the
 //      selection runs over 8 x 32 keys.
 // out: LDS [k], sorted, KEY_PAD padded.
-#define MERGE_FAST_K 32
+#define MERGE_FAST_K 40 /* >= the most keys one scan pass selects (36) */
 #define MERGE_PRE 8
 struct MergeFastScratch {
     u64 wl[MERGE_THREADS / 64][MERGE_FAST_K];
@@ -172,11 +172,13 @@ __device__ __forceinline__ void merge_waves(const MergeParams& p, const u64* bas
         if (lane < MERGE_FAST_K) s.wl[w][lane] = mine;  // lanes >= k hold KEY_PAD
         __syncthreads();
         if (w == 0) {
-            u64 kk[4];
+            constexpr int KPLM = (NW * MERGE_FAST_K + 63) / 64;
+            static_assert(NW * MERGE_FAST_K % 64 == 0, "the waves' lists fill whole registers");
+            u64 kk[KPLM];
 #pragma unroll
-            for (int e = 0; e < 4; e++) kk[e] = (&s.wl[0][0])[lane + 64 * e];
+            for (int e = 0; e < KPLM; e++) kk[e] = (&s.wl[0][0])[lane + 64 * e];
             u64 kth_unused;
-            const int nw = wave_select<4>(kk, NW * MERGE_FAST_K, k, out, &kth_unused);
+            const int nw = wave_select<KPLM>(kk, NW * MERGE_FAST_K, k, out, &kth_unused);
             if (lane >= nw && lane < k) out[lane] = KEY_PAD;
         }
         __syncthreads();

@@ -31,7 +31,7 @@ struct ScanParams {
 
 #define CAP 16       /* slots of a wave's private candidate list; folded out at MERGE_TRIG */
 #define MERGE_TRIG 12
-#define KB_MAX 32    /* block-list slots per query (runtime kb = 16 or 32), >= k of one pass */
+#define KB_MAX 48    /* block-list slots per query (runtime kb = 16, 32 or 48), >= k of one pass; KB_MAX + CAP <= 64 */
 
 #define LDS_LIMIT (160 * 1024)
 

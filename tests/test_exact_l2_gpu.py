@@ -623,3 +623,47 @@ def test_bf16_large_batch_overflow_reruns_through_the_streaming_passes(faiss):
     assert (I == dup[:k][None, :]).all(), "ties must resolve to the lowest ids"
     D_ref, I_ref = ko.knn_exact(rb, rq, k, ko.METRIC_INNER_PRODUCT)
     assert_knn_matches(D, I, D_ref, I_ref, rb, rq, ko.METRIC_INNER_PRODUCT)
+
+
+@pytest.mark.parametrize("d,nq,k", [(512, 256, 10), (512, 1024, 10), (128, 300, 32), (384, 257, 1), (256, 1100, 5)])
+def test_f32_inner_product_large_batch_gemm_path(faiss, d, nq, k):
+    """The reference's default index type is "cosine" -- IndexFlatIP over normalised rows
+    (backend/utils.py:293,300-303; backend/siamese/test_index.py:52-56).  Batches of >= 256 queries against float32
+    inner-product rows take the GEMM-shaped pass (csrc/ise_gemm_scan.hpp, IPM) instead of re-reading the index per 48
+    queries: same answers as the oracle, and bit for bit those of the streaming passes (the kernel sums a dot product
+    in scan_kernel's order), which batches of 128 still take."""
+    rng = np.random.default_rng(d + nq + k)
+    n = 150_000
+    xb = ko.normalize_rows(rng.standard_normal((n, d)).astype(np.float32))
+    xq = ko.normalize_rows(rng.standard_normal((nq, d)).astype(np.float32))
+    IP = ko.METRIC_INNER_PRODUCT
+    index = faiss.IndexFlatIP(d)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    assert index.exact_stats()["gemm_chunks"] == (nq + 1023) // 1024
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, IP)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, IP, gap=ko.kth_gap(xb, xq, k, IP))
+    before = index.exact_stats()["gemm_chunks"]
+    Ds = np.concatenate([index.search(xq[i:i + 128], k)[0] for i in range(0, nq, 128)])
+    Is = np.concatenate([index.search(xq[i:i + 128], k)[1] for i in range(0, nq, 128)])
+    assert index.exact_stats()["gemm_chunks"] == before, "batches of 128 must take the streaming passes"
+    assert np.array_equal(Is, I) and np.array_equal(Ds, D)
+
+
+def test_f32_inner_product_large_batch_overflow_reruns_through_the_streaming_passes(faiss):
+    """5000 copies of one row: every copy passes any query's admit threshold, the candidate buffers overflow, and
+    the streaming passes queued behind the GEMM-shaped pass (gated on the overflow) answer instead -- lowest ids first."""
+    rng = np.random.default_rng(18)
+    n, d, nq, k = 140_000, 128, 256, 10
+    IP = ko.METRIC_INNER_PRODUCT
+    xb = ko.normalize_rows(rng.standard_normal((n, d)).astype(np.float32))
+    dup = np.sort(rng.choice(n, 5000, replace=False))
+    xb[dup] = xb[dup[0]]
+    xq = np.ascontiguousarray(np.repeat(xb[dup[0]][None, :], nq, axis=0) + 0.001 * rng.standard_normal((nq, d)).astype(np.float32))
+    index = faiss.IndexFlatIP(d)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    assert index.exact_stats()["gemm_chunks"] == 1
+    assert (I == dup[:k][None, :]).all(), "ties must resolve to the lowest ids"
+    D_ref, I_ref = ko.knn_exact(xb, xq, k, IP)
+    assert_knn_matches(D, I, D_ref, I_ref, xb, xq, IP)
