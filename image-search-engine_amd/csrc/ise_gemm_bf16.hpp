@@ -59,7 +59,11 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
 
     auto stage_load = [&](int st, float* dst) {
         const char* src = reinterpret_cast<const char*>(p.qprep) + (size_t)st * GB_GQ * S * 4;
-        const int bytes = GB_GQ * S * 4;
+        int bytes = GB_GQ * S * 4;
+#ifdef ISE_ABLATE
+        if (p.ablate & 8) bytes >>= 1;   // dev: half the stage (timing only: is the pass bound by the LDS-DMA fill?)
+        if (p.ablate & 16) bytes >>= 2;  // dev: a quarter
+#endif
         for (int off = w * 1024; off < bytes; off += 8 * 1024)
             if (off + lane * 16 < bytes)
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + off + lane * 16),
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
             if (!(p.ablate & 2))
 #endif
             stage_load(sq + 1 == st1 ? st0 : sq + 1, nxt);
+            unsigned younger = 0;  // stores issued behind that DMA (wait_stage_dma, ise_gemm_scan.hpp)
 
           for (int half = 0; half < GB_GQ / 32; half++) {  // 32 queries at a time: two query tiles
             const float* q0 = cur + (size_t)(half * 32 + c) * S + 4 * g;
@@ -118,40 +123,44 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
             for (int xt = 0; xt < GB_XT; xt++)
 #pragma unroll
                 for (int t = 0; t < 2; t++) acc[xt][t][0] = acc[xt][t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // B fragments are requested TWO k-steps ahead: a k-step is only 4 MFMAs x 16 cycles, less than an
-            // LDS round trip (the float32 kernel's 8 x 32 cycles cover it with one step of lookahead)
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(q0), b1 = *reinterpret_cast<const f32x4*>(q1);
-            f32x4 c0 = b0, c1 = b1;
-            if (NS > 1) {
-                c0 = *reinterpret_cast<const f32x4*>(q0 + 16);
-                c1 = *reinterpret_cast<const f32x4*>(q1 + 16);
-            }
+            // B fragments are requested LOOK k-steps ahead of the MFMAs that use them: a k-step is only 4 MFMAs x
+            // 16 cycles, less than an LDS round trip.  The reads and their waits are inline asm: left to hipcc,
+            // every k-step began with s_waitcnt lgkmcnt(0) -- a wait for the reads just issued, no lookahead at
+            // all (SQ_WAIT_ANY 41 % of the wave cycles, MFMA pipe 44 % busy).  LDS operations of a wave retire in
+            // issue order, so "at most 2 * (steps requested behind s) outstanding" means step s has landed; the
+            // waits take the fragments as operands, so nothing that uses them moves in front.
+            constexpr int LOOK = 3;
+            const uint32_t la0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)q0;
+            const uint32_t la1 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)q1;
+            f32x4 bq[NS][2];
+            auto issue = [&](int s_) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bq[s_][0]) : "v"(la0 + 64u * (uint32_t)s_));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bq[s_][1]) : "v"(la1 + 64u * (uint32_t)s_));
+            };
+#pragma unroll
+            for (int s = 0; s < LOOK && s < NS; s++) issue(s);
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                f32x4 n0 = c0, n1 = c1;
-                if (s + 2 < NS) {
-                    n0 = *reinterpret_cast<const f32x4*>(q0 + 16 * (s + 2));
-                    n1 = *reinterpret_cast<const f32x4*>(q1 + 16 * (s + 2));
-                }
-                const bf16x8 bv0 = __builtin_bit_cast(bf16x8, b0), bv1 = __builtin_bit_cast(bf16x8, b1);
+                if (s + LOOK < NS) issue(s + LOOK);
+                const int behind = (NS - 1 - s) < LOOK ? (NS - 1 - s) : LOOK;  // steps requested after step s
+                if (behind >= 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bq[s][0]), "+v"(bq[s][1]));
+                else if (behind == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[s][0]), "+v"(bq[s][1]));
+                else if (behind == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bq[s][0]), "+v"(bq[s][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[s][0]), "+v"(bq[s][1]));
+                const bf16x8 bv0 = __builtin_bit_cast(bf16x8, bq[s][0]), bv1 = __builtin_bit_cast(bf16x8, bq[s][1]);
 #pragma unroll
                 for (int xt = 0; xt < GB_XT; xt++) {
                     const bf16x8 av = __builtin_bit_cast(bf16x8, a[xt][s]);
 #ifdef ISE_ABLATE
                     if (p.ablate & 4) {  // operands stay live, no matrix work
-                        acc[xt][0][s & 1] += __builtin_bit_cast(f32x4, a[xt][s]) + b0;
-                        acc[xt][1][s & 1] += b1;
+                        acc[xt][0][s & 1] += __builtin_bit_cast(f32x4, a[xt][s]) + bq[s][0];
+                        acc[xt][1][s & 1] += bq[s][1];
                         continue;
                     }
 #endif
                     acc[xt][0][s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv0, acc[xt][0][s & 1], 0, 0, 0);
                     acc[xt][1][s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv1, acc[xt][1][s & 1], 0, 0, 0);
                 }
-                b0 = c0;
-                b1 = c1;
-                c0 = n0;
-                c1 = n1;
-                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int xt = 0; xt < GB_XT; xt++)
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
                         for (int j = 0; j < 4; j++) o[j] = (j < nv[xt] && sc[j] < FLT_MAX) ? sc[j] : FLT_MAX;
                         *reinterpret_cast<f32x4*>(p.dump + (size_t)q * ((size_t)p.slabs * ROWS) + (size_t)slab * ROWS +
                                                   w * (GB_XT * 16) + xt * 16 + 4 * g) = o;
+                        younger++;
                     } else if (__ballot(any)) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
@@ -201,13 +211,14 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
                                     e[3] = 0u;
                                     wmine[at] = e;
                                 }
+                                if (wfill < (unsigned)p.capw) younger++;  // the lowest passing lane stored: the instruction was issued
                                 wfill += (unsigned)__popcll(m);
                             }
                         }
                     }
                 }
           }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_stage_dma(younger);
             __syncthreads();
             buf ^= 1;
         }
