@@ -162,3 +162,46 @@ def test_concurrent_describe_calls_share_a_forward_pass(cnn):
         for f in out[i]:
             assert f.shape == (2048,) and torch.allclose(f, a, rtol=1e-3, atol=1e-3 * float(a.abs().max()))
     assert cnn.combined_batches >= 1 and cnn.combined_calls >= 2 * cnn.combined_batches
+
+
+def test_preprocessing_stays_within_one_level_of_the_cv2_restatement():
+    """VERDICT r2 item 8 -- PARITY UNPINNED (cv2 and albumentations are not installed; the reference holds no
+    preprocessed fixture): the product resizes float pixels with ``F.interpolate(bilinear, align_corners=False)``,
+    the reference with cv2's uint8 INTER_LINEAR (11-bit fixed-point coefficients, rounded to uint8,
+    backend/descriptors.py:155,185), restated in oracle/cv2_resize_oracle.py.  On seeded images of the sizes
+    the feed sees (up- and down-scaling, odd sizes, an exact 2x reduction -- where cv2 averages 2 x 2 boxes
+    instead) the two differ by at most ONE uint8 level before normalisation, i.e. <= 1 / (255 std) after it;
+    same-size images are bit-identical."""
+    import torch
+
+    from image_search_engine_amd.descriptors import CNNDescriptor
+    from oracle import cv2_resize_oracle as co
+
+    desc = CNNDescriptor(device="cpu")
+    rng = np.random.default_rng(7)
+    std255 = (co.STD * 255.0).reshape(3, 1, 1)
+    mean255 = (co.MEAN * 255.0).reshape(3, 1, 1)
+    worst = {}
+    for (h, w) in ((375, 500), (500, 375), (224, 224), (100, 80), (448, 448), (640, 427), (31, 1000)):
+        # natural-image-like content (smooth + texture + edges): random low-frequency field plus noise
+        base = rng.random((max(2, h // 16), max(2, w // 16), 3))
+        img = torch.nn.functional.interpolate(torch.from_numpy(base).permute(2, 0, 1)[None], size=(h, w),
+                                              mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+        img = np.clip(img * 255.0 + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+        img[h // 3: h // 3 + 2] = 255                     # a hard edge
+        got = desc._preprocess_batch([img])[0].numpy()    # (3, 224, 224) normalised
+        want = co.preprocess(img)
+        levels = np.abs(got * std255 + mean255 - (want * std255 + mean255))   # back in uint8 levels
+        if (h, w) == (448, 448):
+            # the exact 2x reduction: cv2 switches to the 2 x 2 box average, bilinear at the centre of the
+            # box is the same average -- up to the uint8 rounding
+            assert levels.max() <= 0.5 + 1e-3, levels.max()
+        worst[(h, w)] = float(levels.max())
+        assert levels.max() <= 1.0 + 1e-3, ((h, w), levels.max())
+        assert np.abs(got - want).max() <= 1.0 / std255.min() + 1e-4
+    assert worst[(224, 224)] <= 1e-4                      # no resize: only the normalisation's rounding
+    # and the restatement's own invariants: constant images stay constant, the output is uint8 within range
+    flat = np.full((50, 70, 3), 137, np.uint8)
+    assert (co.resize_linear_u8(flat, (224, 224)) == 137).all()
+    up = co.resize_linear_u8(np.array([[[0, 0, 0], [255, 255, 255]]], np.uint8), (4, 1))
+    assert up.shape == (1, 4, 3) and up[0, 0, 0] == 0 and up[0, 3, 0] == 255 and (np.diff(up[0, :, 0].astype(int)) >= 0).all()
