@@ -109,13 +109,31 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
         for (int sq = st0; sq < st1; sq++) {
             float* cur = buf ? qbuf1 : qbuf0;
             float* nxt = buf ? qbuf0 : qbuf1;
+            // The next stage's LDS-DMA is issued by the first wave of every SIMD (waves 0-3) at the start of this
+            // stage and by the second one (waves 4-7) half a stage later: a wave's eight or nine DMA pieces hold
+            // its instruction stream for hundreds of cycles, and with both partners of a SIMD issuing them together
+            // (they leave the barrier together) the matrix pipe had nothing to do meanwhile.
+            const bool late = w >= 4;
+            bool staged = false;
 #ifdef ISE_ABLATE
-            if (!(p.ablate & 2))
+            if (p.ablate & 2) staged = true;
+            if (p.ablate & 32) {  // dev: every wave at the start of the stage (the round-2 order)
+                if (!staged) stage_load(sq + 1 == st1 ? st0 : sq + 1, nxt);
+                staged = true;
+            }
 #endif
-            stage_load(sq + 1 == st1 ? st0 : sq + 1, nxt);
+            if (!late && !staged) {
+                stage_load(sq + 1 == st1 ? st0 : sq + 1, nxt);
+                staged = true;
+            }
             unsigned younger = 0;  // stores issued behind that DMA (wait_stage_dma, ise_gemm_scan.hpp)
 
           for (int half = 0; half < GB_GQ / 32; half++) {  // 32 queries at a time: two query tiles
+            if (half == 1 && !staged) {
+                stage_load(sq + 1 == st1 ? st0 : sq + 1, nxt);
+                staged = true;
+                younger = 0;  // the appends of the first half are older than the DMA
+            }
             const float* q0 = cur + (size_t)(half * 32 + c) * S + 4 * g;
             const float* q1 = q0 + (size_t)16 * S;
             f32x4 acc[GB_XT][2][2];  // [row tile][query tile][k-step parity]: the streaming kernel's two chains
