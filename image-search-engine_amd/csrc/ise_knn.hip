@@ -579,7 +579,7 @@ struct EnvKnobs {
     std::atomic<int> no_direct{0};      // ISE_NO_DIRECT=1: one-query batches take the filtered path as well
     std::atomic<int> no_short{0};       // ISE_NO_SHORT=1: short indexes take the streaming kernel + merge launches
     std::atomic<int> short_tpb_max{0};  // ISE_SHORT_TPB_MAX: most row tiles per block the short-index kernel takes
-    std::atomic<int> direct_min_tiles{0};  // ISE_DIRECT_MIN_TILES: shortest index (16-row tiles) the direct one-query scan takes
+    std::atomic<int> direct_short_max_tiles{0};  // ISE_DIRECT_SHORT_MAX_TILES: longest SHORT index (16-row tiles) whose one-query batches take the direct scan
     void refresh() {
         auto flag = [](const char* name) { const char* e = getenv(name); return (e && e[0] == '1') ? 1 : 0; };
         auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
@@ -587,7 +587,7 @@ struct EnvKnobs {
         no_direct.store(flag("ISE_NO_DIRECT"));
         no_short.store(flag("ISE_NO_SHORT"));
         short_tpb_max.store(num("ISE_SHORT_TPB_MAX"));
-        direct_min_tiles.store(num("ISE_DIRECT_MIN_TILES"));
+        direct_short_max_tiles.store(num("ISE_DIRECT_SHORT_MAX_TILES"));
     }
 };
 static EnvKnobs& knobs() {
@@ -698,17 +698,20 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
         const int S = qs_stride_for(h);
         // shapes tried in order: one 16-wave block per CU (the queries are staged once per CU, one query per
         // wave in the selection, half the lists for the merge: 36.3 us per step at 100k x 512 against 42.0 with two
-        // 8-wave blocks per CU and 44.2 with three), two 8-wave blocks per CU (up to 262k rows), one 8-wave block
-        // per CU (long rows: the query tile alone takes most of the LDS).  The row tiles are split evenly over the
-        // blocks: the stream is bound per CU, so every CU gets the same bytes (within one tile).
-        static const int shapes[3][2] = {{16, 1}, {8, 2}, {8, 1}};  // waves, blocks per CU
-        int first = 0;
+        // 8-wave blocks per CU and 44.2 with three), then two 8-wave blocks per CU (up to 262k rows).  The row tiles
+        // are split evenly over the blocks: the stream is bound per CU, so every CU gets the same bytes (within one
+        // tile).  Rows of more than 2 KB keep the streaming kernel (and the direct scan for one query): staging a
+        // 16-query tile of such rows per block costs more than the bookkeeping it saves (30k x 1024: 77 against
+        // 68 us per batch of 16; 100k x 2048, the reference's own descriptor size: 318 against 245, and 291 against
+        // 166 us for one query, scripts/long_rows_probe.py).
+        static const int shapes[2][3] = {{16, 1, 1}, {8, 2, 1}};  // waves, blocks per CU, rounds over the CUs
+        int first = row_bytes(h) <= 2048 ? 0 : 2;
 #ifdef ISE_ABLATE
-        if (const char* e = getenv("ISE_SHORT_SHAPE")) first = std::max(0, std::min(2, atoi(e)));  // dev: skip shapes
+        if (const char* e = getenv("ISE_SHORT_SHAPE")) first = std::max(first, std::min(1, atoi(e)));  // dev: skip shapes
 #endif
-        for (int si = first; si < 3 && !pl->short_; si++) {
+        for (int si = first; si < 2 && !pl->short_; si++) {
             const int wv = shapes[si][0], bpc = shapes[si][1];
-            int nbs = std::max(1, std::min(h->num_cu * bpc, (pl->tiles_total + wv - 1) / wv));
+            int nbs = std::max(1, std::min(h->num_cu * bpc * shapes[si][2], (pl->tiles_total + wv - 1) / wv));
             nbs = std::min(nbs, MERGE_LISTS_MAX);
             const int tpb = (pl->tiles_total + nbs - 1) / nbs;
             const size_t lds = short_lds_layout(S, tpb, wv);
@@ -917,10 +920,13 @@ static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, con
     // one query only: two to four queries are VALU-bound here (380-520 us) and faster through the filter (356 us)
     // (ISE_FORCE_EXACT asks for the filtered path's fallback to be exercised: it implies the filtered path)
     if (!pl.exact || nq != 1 || k > XPASS_MAX || h->n <= 0 || !w->fl_state || no_direct() || force_exact()) return false;
-    // short indexes: the filtered search behind the short-index kernel (ise_short_scan.hpp) is faster than this
-    // scan's serial tail (100k x 512: 56.9 us per step direct); $ISE_DIRECT_MIN_TILES moves the crossover
-    const int min_tiles = knobs().direct_min_tiles.load(std::memory_order_relaxed);
-    if (pl.short_ && (min_tiles <= 0 || pl.tiles_total < min_tiles)) return false;
+    // One query against a short index: up to ~16k rows the direct scan -- ONE launch, no merge, no gate -- has the
+    // lower latency (1000 x 512: 35.8 against 42.6 us per call; 10k: 39.4 against 43.5); beyond, its serial tail
+    // (the last block folds 512 lists) loses to the filtered search behind short_scan_kernel (100k x 512: 56.8
+    // against 36.1 us per step).  $ISE_DIRECT_SHORT_MAX_TILES moves the crossover.
+    int max_tiles = knobs().direct_short_max_tiles.load(std::memory_order_relaxed);
+    if (max_tiles <= 0) max_tiles = 1024;
+    if (pl.short_ && pl.tiles_total > max_tiles) return false;
     // >= 64 rows per block (4 waves x XR rows x 4 steps), at most the merge's list count
     long long blocks = std::min<long long>(MERGE_LISTS_MAX, (h->n + 63) / 64);
     static const long long per_cu = [] { const char* e = getenv("ISE_DIRECT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return (long long)(v > 0 ? v : 2); }();

@@ -103,7 +103,7 @@ int ise_index_stats(ise_index_t* h, uint64_t* out4);
 int ise_index_short_stats(ise_index_t* h, uint64_t* out1);
 
 /* Test / rehearsal knobs ($ISE_FORCE_EXACT, $ISE_NO_DIRECT, $ISE_NO_SHORT, $ISE_SHORT_TPB_MAX,
- * $ISE_DIRECT_MIN_TILES) are read from the environment when the library is first used and again when
+ * $ISE_DIRECT_SHORT_MAX_TILES) are read from the environment when the library is first used and again when
  * this is called -- never inside a search. */
 int ise_refresh_env_knobs(void);
 

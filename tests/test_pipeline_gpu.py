@@ -407,8 +407,9 @@ def test_config2_cnn_embeddings_to_l2_index_end_to_end():
     D0, I0 = index.search(xb[17:18], 1)
     assert I0[0, 0] == 17 and D0[0, 0] == 0.0
     st = index.exact_stats()
-    # both batches (nq queries, then one) were scanned by the short-index kernel
-    assert st["reranked"] == nq + 1 and index.short_stats() == {"short_batches": 2}
+    # the batch of nq queries was scanned by the short-index kernel, the one-query batch (3000 rows) by the direct scan
+    assert st["reranked"] == nq and index.short_stats() == {"short_batches": 1}
+    assert index.host_stats()["direct_queries"] == 1
 
 
 def test_config2_at_full_size():

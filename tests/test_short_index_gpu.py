@@ -44,9 +44,9 @@ def _data(rng, n, d, nq, unit):
     return xb, xq
 
 
-SHAPES = [  # n, d: block counts from 1 to the full grid, tails in rows and in columns, the longest rows
-    (1, 8), (15, 3), (16, 32), (17, 100), (129, 128), (1000, 2048), (4097, 512), (30_000, 200),
-    (100_000, 128), (200_000, 64), (20_000, 2100),
+SHAPES = [  # n, d: block counts from 1 to the full grid, tails in rows and in columns, rows up to the 2 KB limit
+    (1, 8), (15, 3), (16, 32), (17, 100), (129, 128), (1000, 512), (4097, 512), (30_000, 200),
+    (100_000, 128), (200_000, 64), (20_000, 500),
 ]
 
 
@@ -69,8 +69,10 @@ def test_short_kernel_equals_the_streaming_path_and_the_oracle(faiss, metric, st
     launched = index.short_stats()["short_batches"]
     for nq, k in ((1, 10), (5, 1), (16, 10), (16, kmax), (7, 3)):
         xq, xq_r = xq_all[:nq], xq_r_all[:nq]
+        # one float32 L2 query against an index of up to 16k rows is answered by the direct scan (one launch)
+        short = not (nq == 1 and metric == L2 and storage == "f32" and n <= 16384)
         D, I = index.search(xq, k)
-        launched += 1
+        launched += 1 if short else 0
         assert index.short_stats() == {"short_batches": launched}, (nq, k)
         with no_short():
             Ds, Is = index.search(xq, k)
@@ -79,29 +81,38 @@ def test_short_kernel_equals_the_streaming_path_and_the_oracle(faiss, metric, st
         D_ref, I_ref = ko.knn_exact(xb_r, xq_r, k, metric)
         assert_knn_matches(D, I, D_ref, I_ref, xb_r, xq_r, metric, gap=ko.kth_gap(xb_r, xq_r, k, metric) if n > 1 else None)
         keys = index.search_keys_torch(torch.from_numpy(xq).cuda(), k, 12345)
-        launched += 1
+        launched += 1 if short else 0
         Dm, Im = faiss.merge_keys_torch(keys[None], metric)
         assert np.array_equal(Im.cpu().numpy(), np.where(I >= 0, I + 12345, -1)) and np.array_equal(Dm.cpu().numpy(), D)
 
 
 def test_what_does_not_take_the_short_kernel(faiss):
-    """17 queries (two query tiles), k whose candidates need two passes, and an index with more than 32 row tiles
-    per block keep the streaming kernels; the answers still agree with the oracle."""
+    """17 queries (two query tiles), k whose candidates need two passes, an index with more than 32 row tiles
+    per block and rows of more than 2 KB keep the streaming kernels; the answers still agree with the oracle."""
     rng = np.random.default_rng(8)
     xb, xq = _data(rng, 50_000, 64, 17, unit=False)
     index = faiss.IndexFlatL2(64)
     index.add(xb)
-    for nq, k in ((17, 10), (4, 29), (16, 100)):
+    for nq, k in ((17, 10), (4, 33), (16, 100)):
         D, I = index.search(xq[:nq], k)
         D_ref, I_ref = ko.knn_exact(xb, xq[:nq], k, L2)
         assert_knn_matches(D, I, D_ref, I_ref, xb, xq[:nq], L2, gap=ko.kth_gap(xb, xq[:nq], k, L2), atol=ATOL_UNIFORM)
     assert index.short_stats()["short_batches"] == 0
-    D, I = index.search(xq[:16], 28)
+    D, I = index.search(xq[:16], 32)                       # k = 32 + 4 spare candidates: still one pass
     assert index.short_stats()["short_batches"] == 1
     big = faiss.IndexFlatL2(16)
     big.add(rng.random((300_000, 16), dtype=np.float32))   # 18750 row tiles: 37 per block even with 512 blocks
     big.search(xq[:4, :16].copy(), 5)
     assert big.short_stats()["short_batches"] == 0
+    wide = faiss.IndexFlatL2(2048)                          # the reference's own descriptor size: 8 KB rows
+    xw = rng.random((3000, 2048), dtype=np.float32)
+    wide.add(xw)
+    Dw, Iw = wide.search(xw[5:9] + np.float32(0.001), 10)
+    assert wide.short_stats()["short_batches"] == 0 and Iw[:, 0].tolist() == [5, 6, 7, 8]
+    wide16 = faiss.IndexFlat(1024, L2, storage="bf16")      # 2 KB rows in bf16: still the short kernel
+    wide16.add(xw[:, :1024].copy())
+    wide16.search(xw[5:9, :1024].copy(), 10)
+    assert wide16.short_stats()["short_batches"] == 1
     with env_knob("ISE_SHORT_TPB_MAX", 4):                  # the knob lowers the limit (A/B runs)
         index.search(xq[:16], 10)                           # 3125 row tiles: 8 per block at best
     assert index.short_stats()["short_batches"] == 1
