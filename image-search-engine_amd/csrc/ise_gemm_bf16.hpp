@@ -88,10 +88,10 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
     const u64 lt_mask = (1ull << lane) - 1ull;
     const char* xbytes = reinterpret_cast<const char*>(p.xb);
     const size_t row_b = (size_t)p.dp * 2;
+    u32x4 a[GB_XT][NS];
+    f32x4 yn[GB_XT];
     for (int slab = first; slab < p.slabs; slab += step) {
         const long long row_base = (long long)slab * p.slab_stride * ROWS + w * (GB_XT * 16);
-        u32x4 a[GB_XT][NS];
-        f32x4 yn[GB_XT];
         int nv[GB_XT];  // valid rows among this lane's four of each tile: the per-element bound check, once per slab
 #pragma unroll
         for (int xt = 0; xt < GB_XT; xt++) {
@@ -99,6 +99,9 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
             nv[xt] = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
             const long long rr = min(row_base + xt * 16 + c, p.rows16 - 1);
             const char* rp = xbytes + (size_t)rr * row_b + 16 * g;
+#ifdef ISE_ABLATE
+            if ((p.ablate & 64) && slab != first) continue;  // dev: the row tiles are loaded once (timing only)
+#endif
 #pragma unroll
             for (int s = 0; s < NS; s++) a[xt][s] = *reinterpret_cast<const u32x4*>(rp + 64 * s);
             yn[xt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -194,19 +197,22 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
                     const int q = sq * GB_GQ + half * 32 + t * 16 + c;
                     const float xq_n = l2 ? xnL[q] : 0.f, tq = tauL[q];
                     const long long r0 = row_base + xt * 16 + 4 * g;
+                    // fast reject on the lane's BEST of its four rows (three instructions for the inner product: a
+                    // max3, a max and a compare against -tau; rows past the end only ever make it say "maybe"): the
+                    // per-row tests run only for the tiles the ballot lets through
                     float sc[4];
-                    bool pass[4];
-                    bool any = false;
+                    float best;
+                    if (l2) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (l2) {
+                        for (int j = 0; j < 4; j++) {
                             const float v = (xq_n + yn[xt][j]) - 2.f * dot[j];
                             sc[j] = v < 0.f ? 0.f : v;  // keeps NaN
-                        } else {
-                            sc[j] = -dot[j];
                         }
-                        pass[j] = sc[j] <= tq && j < nv[xt];
-                        any |= pass[j];
+                        best = fminf(fminf(sc[0], sc[1]), fminf(sc[2], sc[3]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) sc[j] = -dot[j];
+                        best = -fmaxf(fmaxf(dot[0], dot[1]), fmaxf(dot[2], dot[3]));
                     }
                     if constexpr (DUMP) {
                         f32x4 o;
@@ -215,13 +221,14 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
                         *reinterpret_cast<f32x4*>(p.dump + (size_t)q * ((size_t)p.slabs * ROWS) + (size_t)slab * ROWS +
                                                   w * (GB_XT * 16) + xt * 16 + 4 * g) = o;
                         younger++;
-                    } else if (__ballot(any)) {
+                    } else if (__ballot(best <= tq)) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const u64 m = __ballot(pass[j]);
+                            const bool pass_j = sc[j] <= tq && j < nv[xt];
+                            const u64 m = __ballot(pass_j);
                             if (m) {
                                 const unsigned at = wfill + (unsigned)__popcll(m & lt_mask);
-                                if (pass[j] && at < (unsigned)p.capw) {
+                                if (pass_j && at < (unsigned)p.capw) {
                                     u32x4 e;
                                     e[0] = (uint32_t)((uint32_t)(r0 + j) + p.id_base);
                                     e[1] = ord_f32(sc[j]);

@@ -1,6 +1,6 @@
 """Randomised differential run of the LARGE-BATCH paths (nq >= 128 against >= 128k rows: GEMM-shaped passes, threshold
-sample, candidate buffers, re-rank, exact-scan fallback) against the C oracle on the GPU box's cores.  float32 L2 and
-bf16 inner product; uniform / offset / clustered / duplicated rows; queries near rows, far from all rows, duplicated."""
+sample, candidate buffers, re-rank, exact-scan fallback) against the C oracle on the GPU box's cores.  float32 L2,
+float32 inner product and bf16 inner product; uniform / offset / clustered / duplicated rows; queries near rows, far from all rows, duplicated."""
 import os, sys, time, traceback
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,12 +16,14 @@ stats = {"gemm_chunks": 0, "exact_scan": 0}
 while time.time() < t_end:
     case += 1
     rng = np.random.default_rng(seed0 * 104729 + case)
-    bf16 = rng.random() < 0.3
-    metric = 0 if bf16 else 1
+    kind = rng.random()
+    bf16 = kind < 0.3
+    f32ip = 0.3 <= kind < 0.55
+    metric = 0 if (bf16 or f32ip) else 1
     d = int(rng.choice([128, 256, 384, 512]))
     n = int(rng.choice([131072, 140001, 200000, 262144 + 17]))
     nq = int(rng.choice([128, 256, 257, 300, 512, 1024, 1100]))
-    k = int(rng.choice([1, 5, 10, 20, 28]))
+    k = int(rng.choice([1, 5, 10, 20, 28, 32]))
     shape = str(rng.choice(["uniform", "offset", "clusters", "dups"]))
     if shape == "uniform":
         xb = rng.random((n, d), dtype=np.float32)
@@ -33,7 +35,7 @@ while time.time() < t_end:
     else:
         base = rng.random((n // 50, d), dtype=np.float32)
         xb = base[rng.integers(0, base.shape[0], n)]
-    if bf16:
+    if bf16 or f32ip:
         xb = xb - xb.mean(0, keepdims=True)
         xb = xb / np.maximum(np.linalg.norm(xb, axis=1, keepdims=True), 1e-20)
     xb = np.ascontiguousarray(xb, dtype=np.float32)
@@ -45,7 +47,7 @@ while time.time() < t_end:
     else:
         xq = np.repeat(xb[rng.integers(0, n, 1)], nq, axis=0)
     xq = np.ascontiguousarray(xq, dtype=np.float32)
-    desc = f"case {case}: {'bf16 IP' if bf16 else 'f32 L2'} n={n} d={d} nq={nq} k={k} rows={shape} queries={qk}"
+    desc = f"case {case}: {'bf16 IP' if bf16 else ('f32 IP' if f32ip else 'f32 L2')} n={n} d={d} nq={nq} k={k} rows={shape} queries={qk}"
     try:
         index = faiss.IndexFlat(d, metric, storage="bf16" if bf16 else "f32")
         index.add(xb)
