@@ -397,11 +397,13 @@ class Kmeans:
         c = torch.from_numpy(c0).to(x_dev.device)
         obj = []
         n = x_dev.shape[0]
+        # one assignment index for all iterations (its stream and buffers are created once): the centroids are
+        # swapped in with reset() + add
+        index = IndexFlat(self.d, METRIC_INNER_PRODUCT if self.spherical else METRIC_L2, x_dev.device.index)
         for _ in range(niter):
             if self.spherical:
                 normalize_L2(c)
-            index = IndexFlat(self.d, METRIC_INNER_PRODUCT if self.spherical else METRIC_L2,
-                              x_dev.device.index)
+            index.reset()
             index.add_torch(c)
             D, I = index.assign_torch(x_dev) if index._assign_applies(n, 1) else index.search_torch(x_dev, 1)
             lab = I.view(-1).clamp_(min=0)

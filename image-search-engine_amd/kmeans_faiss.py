@@ -16,24 +16,11 @@ What runs where
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-
 import numpy as np
 
 from . import faiss_compat as faiss
 
 _SEED = 42  # backend/kmeans_faiss.py:30
-
-
-@dataclass
-class _TrainSettings:
-    k: int
-    restarts: int
-    iterations: int
-
-    def build(self, d: int) -> "faiss.Kmeans":
-        return faiss.Kmeans(d=d, k=self.k, niter=self.iterations, nredo=self.restarts, seed=_SEED,
-                            spherical=True, verbose=False)
 
 
 class FaissKMeans:
@@ -50,8 +37,8 @@ class FaissKMeans:
     # -- training ("next" row)
     def fit(self, X: np.ndarray, y=None) -> None:
         rows = self._rows(X)
-        settings = _TrainSettings(int(self.n_clusters), int(self.n_init), int(self.max_iter))
-        self.kmeans = settings.build(rows.shape[1])
+        self.kmeans = faiss.Kmeans(d=rows.shape[1], k=int(self.n_clusters), niter=int(self.max_iter),
+                                   nredo=int(self.n_init), seed=_SEED, spherical=True, verbose=False)
         self.kmeans.train(rows, init_centroids=self.init_centroids)
         self.index = self.kmeans.index
         self.cluster_centers_ = self.kmeans.centroids
