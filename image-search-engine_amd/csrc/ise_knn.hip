@@ -122,6 +122,7 @@ struct ise_index {
         // page-locked staging of a combined batch (queries in, results out)
         float* q_pin = nullptr;  size_t q_pin_elems = 0;
         float* D_pin = nullptr;  long long* I_pin = nullptr;  size_t out_pin_elems = 0;
+        float* D_pin_dev = nullptr;  long long* I_pin_dev = nullptr;  // the same buffers as the device addresses them
         bool busy = false;
     };
     static constexpr int NHC = 4;
@@ -736,7 +737,8 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
 // exact path: the fallback list
 static int ensure_workspace(ise_index::WorkSlot* w, const ScanPlan& pl, long long nq, bool* changed) {
     if (!w->done) HIP_TRY(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
-    const size_t need = (size_t)pl.nqt * pl.nblocks * (16 * pl.T) * pl.kpass;
+    // at least what the direct one-query scan can ask for (direct_applies): MERGE_LISTS_MAX lists of XPASS_MAX keys
+    const size_t need = std::max<size_t>((size_t)pl.nqt * pl.nblocks * (16 * pl.T) * pl.kpass, (size_t)MERGE_LISTS_MAX * XPASS_MAX);
     if (need > w->part_elems) {
         if (w->part) (void)hipFree(w->part);  // hipFree waits for outstanding work
         w->part = nullptr;
@@ -927,8 +929,12 @@ static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, con
     int max_tiles = knobs().direct_short_max_tiles.load(std::memory_order_relaxed);
     if (max_tiles <= 0) max_tiles = 1024;
     if (pl.short_ && pl.tiles_total > max_tiles) return false;
-    // >= 64 rows per block (4 waves x XR rows x 4 steps), at most the merge's list count
-    long long blocks = std::min<long long>(MERGE_LISTS_MAX, (h->n + 63) / 64);
+    // rows per block: 64 (4 waves x XR rows x 4 steps) for rows up to 2 KB, down to 16 (one step per wave) for longer
+    // ones -- ~128 KB per block -- so that a small index of long rows (the reference's own: ~1000 x 2048) is spread
+    // over the chip instead of streamed by 16 CUs (1000 x 2048: 44.6 -> see DESIGN.md 4.2); at most the merge's
+    // list count
+    const long long min_rows = std::max<long long>(16, std::min<long long>(64, (128 * 1024) / ((long long)h->dp * 4)));
+    long long blocks = std::min<long long>(MERGE_LISTS_MAX, (h->n + min_rows - 1) / min_rows);
     static const long long per_cu = [] { const char* e = getenv("ISE_DIRECT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return (long long)(v > 0 ? v : 2); }();
     blocks = std::min<long long>(blocks, (long long)h->num_cu * per_cu);
     if ((size_t)nq * blocks * k > w->part_elems) return false;  // the slot's lists are sized for the filter's plan
@@ -1620,8 +1626,10 @@ static int run_combined(ise_index* h, const std::vector<ise_index::HostReq*>& ba
         if (c->I_pin) (void)hipHostFree(c->I_pin);
         c->D_pin = nullptr; c->I_pin = nullptr; c->out_pin_elems = 0;
         const size_t want = std::max<size_t>(oe, (size_t)std::max<long long>(host_combine_max(), 1) * k);
-        HIP_TRY(hipHostMalloc(&c->D_pin, want * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(&c->I_pin, want * sizeof(long long), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&c->D_pin, want * sizeof(float), hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc(&c->I_pin, want * sizeof(long long), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&c->D_pin_dev, c->D_pin, 0));
+        HIP_TRY(hipHostGetDevicePointer((void**)&c->I_pin_dev, c->I_pin, 0));
         c->out_pin_elems = want;
     }
     size_t off = 0;
@@ -1633,11 +1641,11 @@ static int run_combined(ise_index* h, const std::vector<ise_index::HostReq*>& ba
     int rc;
     {
         std::lock_guard<std::mutex> lk(h->mu_);
-        rc = search_enqueue(h, c->q_dev, total, k, 0u, c->D_dev, c->I_dev, nullptr, c->stream, nullptr);
+        // results go straight into the pinned host buffers (mapped, coherent: the last kernel's few hundred bytes
+        // travel as posted writes and are visible when the stream has drained) -- two copy launches less per call
+        rc = search_enqueue(h, c->q_dev, total, k, 0u, c->D_pin_dev, c->I_pin_dev, nullptr, c->stream, nullptr);
     }
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(c->D_pin, c->D_dev, oe * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->I_pin, c->I_dev, oe * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     off = 0;
     for (auto* r : batch) {

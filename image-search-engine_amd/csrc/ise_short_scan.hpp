@@ -65,7 +65,6 @@ __host__ __device__ constexpr size_t short_lds_layout(int S, int tiles_per_block
 template <int CH, int R, int W, int WPS, bool BF16, bool SHIFT>
 __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParams p, const ShortParams tp) {
     static_assert(!(BF16 && SHIFT), "the shift is applied to fp32 rows only");
-    constexpr int BLOCK_THREADS = W * 64;
     constexpr int NQ = 16;
     // 32 threads stage one query row, whatever the block width (a 16-wave block stages with its first 8 waves):
     // the sum of squares |x|^2 then has ONE summation order -- the one of scan_kernel's 8-wave blocks -- and
