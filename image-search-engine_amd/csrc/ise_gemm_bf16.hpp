@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_scan_bf16_kernel(const GemmScanPa
 // One block per query: sort its candidates, emit the k best as they are (no re-rank for bf16 rows / inner
 // product).  Incomplete candidates (an overflowed buffer) raise the rerun flag instead: the host has the
 // streaming passes queued behind this kernel, gated on that flag, and they rewrite every query of the chunk.
-// LDS: capq keys.
+// LDS: capq + 320 keys (candidates, selection scratch, the k best).
 __global__ __launch_bounds__(256) void gemm_select_plain_kernel(const u64* cand, const unsigned int* ccnt, int capq,
                                                                 const unsigned int* overflow, unsigned int* rerun, int k,
                                                                 int metric, float* D, long long* I, u64* keys_out) {
@@ -276,17 +276,15 @@ __global__ __launch_bounds__(256) void gemm_select_plain_kernel(const u64* cand,
         return;
     }
     const int cnt = off[GEMM_SUBS];
-    int n2 = 64;
-    while (n2 < cnt) n2 <<= 1;
-    for (int i = tid; i < n2; i += 256) srt[i] = KEY_PAD;
-    __syncthreads();
 #pragma unroll
     for (int s_ = 0; s_ < GEMM_SUBS; s_++)
         for (int i = tid; i < off[s_ + 1] - off[s_]; i += 256)
             srt[off[s_] + i] = cand[(size_t)q * capq + (size_t)s_ * caps + i];
-    block_sort_u64(srt, n2, tid, 256);
+    __syncthreads();
+    u64* best = srt + capq + 4 * 64;  // [64] behind the candidates and block_topk_u64's scratch
+    block_topk_u64(srt, cnt, k, srt + capq, best);
     for (int r = tid; r < k; r += 256) {
-        const u64 key = r < cnt ? srt[r] : KEY_PAD;
+        const u64 key = best[r];
         const size_t o = (size_t)q * k + r;
         if (keys_out) keys_out[o] = key;
         if (D) {

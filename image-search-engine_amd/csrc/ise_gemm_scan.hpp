@@ -100,15 +100,18 @@ __global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q,
     if (lane == 0) xn[i] = s;
 }
 
-// kc-th smallest of each query's `rows` dumped scores (one block per query):
+// kc-th smallest of each query's `rows` dumped scores (one block per query; the scores are read ONCE, into
+// registers, when rows <= 16384):
 //   1. U = the kc-th smallest of the 256 per-thread minima: at least kc values lie at or below it;
-//   2. the values <= U (about kc * rows / 256 of them... at most KTH_LIST) are collected in LDS and
-//      sorted; the kc-th of them is the answer.  A list that overflows (heavily tied scores) keeps U.
+//   2. the values <= U (about kc * rows / 256 of them... at most KTH_LIST) are collected in LDS (one atomic per
+//      wave and step); block_topk_u64 finds the kc-th of them.  A list that overflows (heavily tied scores) keeps U.
 #define KTH_LIST 2048
+#define KTH_REG 64 /* scores per thread held in registers */
 __global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict__ dump, int rows, int kc, int nq,
                                                          float* __restrict__ tau) {
     __shared__ u64 mins[256];
     __shared__ u64 lst[KTH_LIST];
+    __shared__ u64 stage[4 * 64];
     __shared__ u64 topk[64];
     __shared__ int cnt;
     __shared__ u64 ubound;
@@ -118,9 +121,24 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict
         return;
     }
     const float* src = dump + (size_t)q * rows;
+    const bool in_regs = rows <= KTH_REG * 256;  // block-uniform
     // keys: order-preserving score image in the high word, position in the low word (unique)
+    float v[KTH_REG];
     u64 mn = KEY_PAD;
-    for (int i = tid; i < rows; i += 256) mn = min_u64(mn, ((u64)ord_f32(src[i]) << 32) | (uint32_t)i);
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < KTH_REG; j++) {
+            const int i = tid + 256 * j;
+            v[j] = i < rows ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < KTH_REG; j++) {
+            const int i = tid + 256 * j;
+            if (i < rows) mn = min_u64(mn, ((u64)ord_f32(v[j]) << 32) | (uint32_t)i);
+        }
+    } else {
+        for (int i = tid; i < rows; i += 256) mn = min_u64(mn, ((u64)ord_f32(src[i]) << 32) | (uint32_t)i);
+    }
     mins[tid] = mn;
     if (tid == 0) cnt = 0;
     __syncthreads();
@@ -134,11 +152,28 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict
     }
     __syncthreads();
     const u64 U = ubound;
-    for (int i = tid; i < rows; i += 256) {
-        const u64 key = ((u64)ord_f32(src[i]) << 32) | (uint32_t)i;
-        if (key <= U) {
-            const int at = atomicAdd(&cnt, 1);
-            if (at < KTH_LIST) lst[at] = key;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    auto collect = [&](u64 key, bool valid) {  // wave-uniform call: one LDS atomic per wave and step
+        const bool hit = valid && key <= U;
+        const u64 m = __ballot(hit);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&cnt, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int at = base + __popcll(m & lt_mask);
+            if (hit && at < KTH_LIST) lst[at] = key;
+        }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < KTH_REG; j++) {
+            const int i = tid + 256 * j;
+            collect(((u64)ord_f32(v[j]) << 32) | (uint32_t)i, i < rows);
+        }
+    } else {
+        for (int i0 = 0; i0 < rows; i0 += 256) {
+            const int i = i0 + tid;
+            collect(i < rows ? ((u64)ord_f32(src[i]) << 32) | (uint32_t)i : KEY_PAD, i < rows);
         }
     }
     __syncthreads();
@@ -147,11 +182,8 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict
         if (tid == 0) tau[q] = unord_f32((uint32_t)(U >> 32));
         return;
     }
-    int n2 = 64;
-    while (n2 < n) n2 <<= 1;
-    for (int i = n + tid; i < n2; i += 256) lst[i] = KEY_PAD;
-    block_sort_u64(lst, n2, tid, 256);
-    if (tid == 0) tau[q] = unord_f32((uint32_t)(lst[kc - 1] >> 32));  // n >= kc: the kc minima below U are in the list
+    block_topk_u64(lst, n, kc, stage, topk);  // n >= kc: the kc minima below U are in the list
+    if (tid == 0) tau[q] = unord_f32((uint32_t)(topk[kc - 1] >> 32));
 }
 
 // IPM: float32 INNER PRODUCT rows (the reference's default "cosine" index, backend/utils.py:293,300-303): no
@@ -331,7 +363,7 @@ __global__ __launch_bounds__(256) void regroup_kernel(const u32x4* __restrict__ 
 
 // One block per query: the kc smallest of its candidates (sorted), then the exact re-rank with the
 // threshold as an extra bound.  An overflowed candidate array cannot be trusted: exact scan.
-// LDS: rerank_lds_bytes(dp, kc) followed by capq keys.
+// LDS: rerank_lds_bytes(dp, kc) followed by capq + 256 keys (candidates, selection scratch).
 __global__ __launch_bounds__(256) void gemm_select_kernel(const ExactParams xp, const u64* cand, const unsigned int* ccnt,
                                                           int capq, const unsigned int* overflow) {
     extern __shared__ __align__(16) unsigned char smem_s[];
@@ -351,17 +383,13 @@ __global__ __launch_bounds__(256) void gemm_select_kernel(const ExactParams xp, 
     }
     const int cnt = off[GEMM_SUBS];
     rerank_stage_query<256>(xp, q, smem_s);
-    int n2 = 1;
-    while (n2 < cnt) n2 <<= 1;
-    if (n2 < xp.kc) n2 = rerank_pow2(xp.kc);
-    for (int i = tid; i < n2; i += 256) srt[i] = KEY_PAD;
-    __syncthreads();
 #pragma unroll
     for (int s_ = 0; s_ < GEMM_SUBS; s_++)
         for (int i = tid; i < off[s_ + 1] - off[s_]; i += 256)
             srt[off[s_] + i] = cand[(size_t)q * capq + (size_t)s_ * caps + i];
-    block_sort_u64(srt, n2, tid, 256);
-    for (int i = tid; i < xp.kc; i += 256) kin[i] = srt[i];
+    __syncthreads();
+    // the kc smallest, sorted, into the re-rank's input (cnt <= capq <= 4096; the scratch behind the candidates)
+    block_topk_u64(srt, cnt, xp.kc, srt + capq, kin);
     if (lost) {  // block-uniform
         __syncthreads();
         for (int r = tid; r < xp.k; r += 256) emit_exact(xp, (size_t)q * xp.k + r, KEY_PAD);  // overwritten by the exact scan

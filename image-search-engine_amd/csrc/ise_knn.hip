@@ -1110,7 +1110,7 @@ static int search_large_chunk(ise_index* h, ise_index::WorkSlot* w, const float*
     xp.tau_bound = tau;
     if ((rc = next_fl_seq(w, st, &xp.seq))) return rc;
     hipLaunchKernelGGL(gemm_select_kernel, dim3((unsigned)nq), dim3(256),
-                       rerank_lds_bytes(h->dp, kc) + (size_t)GEMM_CAPQ * 8, st, xp, (const u64*)cand,
+                       rerank_lds_bytes(h->dp, kc) + (size_t)(GEMM_CAPQ + 256) * 8, st, xp, (const u64*)cand,
                        (const unsigned int*)ccnt, GEMM_CAPQ, (const unsigned int*)overflow);
     HIP_TRY(hipGetLastError());
     if ((rc = enqueue_exact_fallback(h, w, pl, xp, nq, st))) return rc;
@@ -1323,7 +1323,7 @@ static int search_large_chunk_bf16(ise_index* h, ise_index::WorkSlot* w, const f
                        (const unsigned int*)gp.wcnt, GEMM_CAPW, cand, ccnt, GEMM_CAPQ, overflow);
     HIP_TRY(hipGetLastError());
     if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
-    hipLaunchKernelGGL(gemm_select_plain_kernel, dim3((unsigned)nq), dim3(256), (size_t)GEMM_CAPQ * 8, st, (const u64*)cand,
+    hipLaunchKernelGGL(gemm_select_plain_kernel, dim3((unsigned)nq), dim3(256), (size_t)(GEMM_CAPQ + 320) * 8, st, (const u64*)cand,
                        (const unsigned int*)ccnt, GEMM_CAPQ, (const unsigned int*)overflow, rerun, k, h->metric, D_dev, I_dev,
                        keys_out);
     HIP_TRY(hipGetLastError());
@@ -1393,7 +1393,7 @@ static int search_large_chunk_ip(ise_index* h, ise_index::WorkSlot* w, const flo
                        (const unsigned int*)gp.wcnt, GEMM_CAPW, cand, ccnt, GEMM_CAPQ, overflow);
     HIP_TRY(hipGetLastError());
     if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e1, st));
-    hipLaunchKernelGGL(gemm_select_plain_kernel, dim3((unsigned)nq), dim3(256), (size_t)GEMM_CAPQ * 8, st, (const u64*)cand,
+    hipLaunchKernelGGL(gemm_select_plain_kernel, dim3((unsigned)nq), dim3(256), (size_t)(GEMM_CAPQ + 320) * 8, st, (const u64*)cand,
                        (const unsigned int*)ccnt, GEMM_CAPQ, (const unsigned int*)overflow, rerun, k, h->metric, D_dev, I_dev,
                        keys_out);
     HIP_TRY(hipGetLastError());

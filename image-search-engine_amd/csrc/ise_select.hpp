@@ -160,3 +160,41 @@ __device__ __forceinline__ int wave_cut(const u64 (&kk)[KPL], int n, int kmin, i
     return cnt;
 }
 
+
+// Block-wide (256 threads = 4 waves): the min(k, n) smallest of the n unique keys list[0 .. n) in LDS, written
+// SORTED to out[0 .. k) (LDS), KEY_PAD behind the last.  Every wave quickselects a quarter of the list
+// (wave_select, keys in registers, no barriers), wave 0 the 4 k winners: two barriers in all, where a bitonic
+// sort of 1024 keys takes 55 (the select kernels of the large-batch paths: 45 -> see DESIGN.md 4.4).
+// n <= 4096 (16 keys per lane), k <= 64; stage: 4 k keys of LDS scratch; `list` is read only.
+template <int KPL>
+__device__ __forceinline__ void block_topk_part(const u64* list, int n, int base, int per, int k, u64* dst) {
+    const int lane = threadIdx.x & 63;
+    u64 kk[KPL];
+#pragma unroll
+    for (int e = 0; e < KPL; e++) {
+        const int idx = base + lane + 64 * e;
+        kk[e] = (64 * e < per && idx < n) ? list[idx] : KEY_PAD;
+    }
+    u64 kth_unused = 0;
+    const int nw = wave_select<KPL>(kk, per < 64 * KPL ? per : 64 * KPL, k, dst, &kth_unused);
+    for (int i = nw + lane; i < k; i += 64) dst[i] = KEY_PAD;
+}
+__device__ __forceinline__ void block_topk_u64(const u64* list, int n, int k, u64* stage, u64* out) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int per = (((n + 3) >> 2) + 63) & ~63;  // a wave's slice: whole rows of 64 keys
+    const int base = w * per;
+    if (per <= 64) block_topk_part<1>(list, n, base, per, k, stage + w * k);
+    else if (per <= 256) block_topk_part<4>(list, n, base, per, k, stage + w * k);
+    else if (per <= 512) block_topk_part<8>(list, n, base, per, k, stage + w * k);
+    else block_topk_part<16>(list, n, base, per, k, stage + w * k);
+    __syncthreads();
+    if (w == 0) {
+        u64 kk[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) kk[e] = (lane + 64 * e) < 4 * k ? stage[lane + 64 * e] : KEY_PAD;
+        u64 kth_unused = 0;
+        const int nw = wave_select<4>(kk, 4 * k, k, out, &kth_unused);
+        for (int i = nw + lane; i < k; i += 64) out[i] = KEY_PAD;
+    }
+    __syncthreads();
+}
