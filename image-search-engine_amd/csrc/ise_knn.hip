@@ -676,15 +676,28 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
         }
     }
 #endif
-    int nb = h->num_cu * blocks_per_cu;
-    const int max_useful = (pl->tiles_total + pl->waves - 1) / pl->waves;
-    if (nb > max_useful) nb = max_useful;
+    // Blocks: one per `waves` row tiles (a tile per wave) on long indexes.  A SMALL index is spread further -- down
+    // to ~64 KB of rows per block (one tile of rows > 2 KB), as long as every block of the launch is resident at
+    // once: the row stream is bound per CU (~30 GB/s), and eight one-tile waves of a 1000 x 2048 index on each of
+    // 8 CUs streamed 33 us where 63 CUs take 8 (the reference's own index size and default metric: 59 -> 34 us
+    // per one-query batch; 1000 x 512, 32 queries: 56 -> 45 us).  More blocks than CUs x blocks_per_cu would run
+    // in rounds: batches of several query tiles (grid.y) divide the budget.
+    const bool long_rows = row_bytes(h) > 2048;
+    const int nqt_plan = (int)((nq + 16 * pl->T - 1) / (16 * pl->T));
+    const int min_tiles = (int)std::max<size_t>(1, 65536 / (16 * row_bytes(h)));
+    const int slots = h->num_cu * blocks_per_cu;
+    const int nb_packed = std::min(slots, (pl->tiles_total + pl->waves - 1) / pl->waves);
+    const int nb_spread = std::min(std::max(1, slots / nqt_plan), (pl->tiles_total + min_tiles - 1) / min_tiles);
+    int nb = std::max(nb_packed, nb_spread);
     if (nb < 1) nb = 1;
     if (nb > MERGE_LISTS_MAX) nb = MERGE_LISTS_MAX;
     pl->tiles_per_block = (pl->tiles_total + nb - 1) / nb;
     if (pl->tiles_per_block < 1) pl->tiles_per_block = 1;
     pl->nblocks = (pl->tiles_total + pl->tiles_per_block - 1) / pl->tiles_per_block;
     if (pl->nblocks < 1) pl->nblocks = 1;
+    // ... and a wave that owns ONE tile of long rows is latency-bound on its own loads: 8-step chunks (2 x 8 KB in
+    // flight) where the register budget has them (8-wave blocks)
+    if (long_rows && pl->T == 1 && pl->waves <= 8 && pl->tiles_per_block <= pl->waves && chunk_steps(h) == 8) pl->ch = 8;
     pl->nqt = (int)((nq + 16 * pl->T - 1) / (16 * pl->T));
     pl->gemm = false;
     pl->gemm_bytes = 0;
@@ -929,11 +942,13 @@ static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, con
     int max_tiles = knobs().direct_short_max_tiles.load(std::memory_order_relaxed);
     if (max_tiles <= 0) max_tiles = 1024;
     if (pl.short_ && pl.tiles_total > max_tiles) return false;
-    // rows per block: 64 (4 waves x XR rows x 4 steps) for rows up to 2 KB, down to 16 (one step per wave) for longer
-    // ones -- ~128 KB per block -- so that a small index of long rows (the reference's own: ~1000 x 2048) is spread
-    // over the chip instead of streamed by 16 CUs (1000 x 2048: 44.6 -> see DESIGN.md 4.2); at most the merge's
-    // list count
-    const long long min_rows = std::max<long long>(16, std::min<long long>(64, (128 * 1024) / ((long long)h->dp * 4)));
+    // rows per block: ~32 KB worth, between 16 (one step per wave) and 64 (4 waves x XR rows x 4 steps), and fewer
+    // than 64 only as far as it takes to put a small index on 64 blocks: the scan of a block is latency-bound, so a
+    // small index wants many blocks (1000 x 2048, the reference's own: 16 blocks 44.6 us, 63 blocks 30; 1000 x 512:
+    // 35.5 -> 28.0 us per call; 1000 x 128: 24.4 -> 18.8), a longer one few lists for the last block to fold
+    // (scripts/host_call_probe.py); at most the merge's list count
+    long long min_rows = std::max<long long>(16, std::min<long long>(64, (32 * 1024) / ((long long)h->dp * 4)));
+    if (h->n < min_rows * 64) min_rows = std::max<long long>(16, h->n / 64);
     long long blocks = std::min<long long>(MERGE_LISTS_MAX, (h->n + min_rows - 1) / min_rows);
     static const long long per_cu = [] { const char* e = getenv("ISE_DIRECT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return (long long)(v > 0 ? v : 2); }();
     blocks = std::min<long long>(blocks, (long long)h->num_cu * per_cu);

@@ -219,22 +219,42 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
                 }
             }
         } else {  // odd d, unaligned queries or very long rows: scalar path, one 4-byte unit at a time
+            // (the loads of SB units are requested together, then consumed in the same ascending order as a
+            // plain loop would: |x|^2 keeps its summation order, the staging of a 2048-float row its round trips
+            // cut by SB -- 8.7 -> see DESIGN.md 4.1)
             const bool rowok = cc < nqt && !ABL(1);
             const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
-            for (int j = t; j < S; j += TPR) {
-                if (BF16) {
-                    const float lo = (rowok && 2 * j < p.d) ? src[2 * j] : 0.f;
-                    const float hi = (rowok && 2 * j + 1 < p.d) ? src[2 * j + 1] : 0.f;
-                    reinterpret_cast<uint32_t*>(qs)[cc * S + j] = to_bf16_pair(lo, hi);
-                    const float r0 = bf16_round(lo), r1 = bf16_round(hi);
-                    sn = fmaf(r0, r0, sn);
-                    sn = fmaf(r1, r1, sn);
-                } else {
-                    const float m = (SHIFT && j < p.d) ? p.mu[j] : 0.f;
-                    const float v = (rowok && j < p.d) ? src[j] - m : 0.f;
-                    qs[cc * S + j] = v;
-                    if (SHIFT && cc == 0) mus[j] = m;
-                    sn = fmaf(v, v, sn);
+            constexpr int SB = 8;
+            for (int j0 = t; j0 < S; j0 += SB * TPR) {
+                float lo[SB], hi[SB], m[SB];
+#pragma unroll
+                for (int b = 0; b < SB; b++) {
+                    const int j = j0 + b * TPR;
+                    lo[b] = hi[b] = m[b] = 0.f;
+                    if (BF16) {
+                        if (rowok && j < S && 2 * j < p.d) lo[b] = src[2 * j];
+                        if (rowok && j < S && 2 * j + 1 < p.d) hi[b] = src[2 * j + 1];
+                    } else {
+                        if (SHIFT && j < S && j < p.d) m[b] = p.mu[j];
+                        if (rowok && j < S && j < p.d) lo[b] = src[j];
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < SB; b++) {
+                    const int j = j0 + b * TPR;
+                    if (j < S) {
+                        if (BF16) {
+                            reinterpret_cast<uint32_t*>(qs)[cc * S + j] = to_bf16_pair(lo[b], hi[b]);
+                            const float r0 = bf16_round(lo[b]), r1 = bf16_round(hi[b]);
+                            sn = fmaf(r0, r0, sn);
+                            sn = fmaf(r1, r1, sn);
+                        } else {
+                            const float v = (rowok && j < p.d) ? lo[b] - m[b] : 0.f;
+                            qs[cc * S + j] = v;
+                            if (SHIFT && cc == 0) mus[j] = m[b];
+                            sn = fmaf(v, v, sn);
+                        }
+                    }
                 }
             }
         }
