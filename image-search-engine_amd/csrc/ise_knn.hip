@@ -725,7 +725,9 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
 #endif
         for (int si = first; si < 2 && !pl->short_; si++) {
             const int wv = shapes[si][0], bpc = shapes[si][1];
-            int nbs = std::max(1, std::min(h->num_cu * bpc * shapes[si][2], (pl->tiles_total + wv - 1) / wv));
+            const int packed = (pl->tiles_total + wv - 1) / wv;
+            const int spread = (pl->tiles_total + min_tiles - 1) / min_tiles;  // as above: >= ~64 KB of rows per block
+            int nbs = std::max(1, std::min(h->num_cu * bpc * shapes[si][2], std::max(packed, spread)));
             nbs = std::min(nbs, MERGE_LISTS_MAX);
             const int tpb = (pl->tiles_total + nbs - 1) / nbs;
             const size_t lds = short_lds_layout(S, tpb, wv);
@@ -935,12 +937,13 @@ static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, con
     // one query only: two to four queries are VALU-bound here (380-520 us) and faster through the filter (356 us)
     // (ISE_FORCE_EXACT asks for the filtered path's fallback to be exercised: it implies the filtered path)
     if (!pl.exact || nq != 1 || k > XPASS_MAX || h->n <= 0 || !w->fl_state || no_direct() || force_exact()) return false;
-    // One query against a short index: up to ~16k rows the direct scan -- ONE launch, no merge, no gate -- has the
-    // lower latency (1000 x 512: 35.8 against 42.6 us per call; 10k: 39.4 against 43.5); beyond, its serial tail
-    // (the last block folds 512 lists) loses to the filtered search behind short_scan_kernel (100k x 512: 56.8
-    // against 36.1 us per step).  $ISE_DIRECT_SHORT_MAX_TILES moves the crossover.
+    // One query against a short index: up to ~4k rows the direct scan -- ONE launch, no merge, no gate -- has the
+    // lower latency (1000 x 512: 21.5 against 25.0 us per call; 4000: 23.3 against 26.7 or 22.5 -- the filtered
+    // path is bimodal by a few us from index to index; 8000: 27.0 against 22.9; 16000: 30.9 against 23.7,
+    // scripts/direct_crossover_probe.py): its time grows with the rows a wave inserts and the lists the last block
+    // folds, the filtered search behind short_scan_kernel stays flat.  $ISE_DIRECT_SHORT_MAX_TILES moves the crossover.
     int max_tiles = knobs().direct_short_max_tiles.load(std::memory_order_relaxed);
-    if (max_tiles <= 0) max_tiles = 1024;
+    if (max_tiles <= 0) max_tiles = 256;
     if (pl.short_ && pl.tiles_total > max_tiles) return false;
     // rows per block: ~32 KB worth, between 16 (one step per wave) and 64 (4 waves x XR rows x 4 steps), and fewer
     // than 64 only as far as it takes to put a small index on 64 blocks: the scan of a block is latency-bound, so a
