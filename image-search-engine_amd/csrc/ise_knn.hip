@@ -937,13 +937,13 @@ static bool direct_applies(const ise_index* h, const ise_index::WorkSlot* w, con
     // one query only: two to four queries are VALU-bound here (380-520 us) and faster through the filter (356 us)
     // (ISE_FORCE_EXACT asks for the filtered path's fallback to be exercised: it implies the filtered path)
     if (!pl.exact || nq != 1 || k > XPASS_MAX || h->n <= 0 || !w->fl_state || no_direct() || force_exact()) return false;
-    // One query against a short index: up to ~4k rows the direct scan -- ONE launch, no merge, no gate -- has the
-    // lower latency (1000 x 512: 21.5 against 25.0 us per call; 4000: 23.3 against 26.7 or 22.5 -- the filtered
-    // path is bimodal by a few us from index to index; 8000: 27.0 against 22.9; 16000: 30.9 against 23.7,
-    // scripts/direct_crossover_probe.py): its time grows with the rows a wave inserts and the lists the last block
-    // folds, the filtered search behind short_scan_kernel stays flat.  $ISE_DIRECT_SHORT_MAX_TILES moves the crossover.
+    // One query against a short index: up to ~2k rows the direct scan -- ONE launch, no merge, no gate -- has the
+    // lower latency, by a microsecond (1000 x 512: 20.6 against 22.1 us per call; 3000: 22.2 against 22.5; 4000:
+    // 23.6 against 22.3; 16000: 30.9 against 23.7, scripts/direct_crossover_probe.py): its time grows with the rows
+    // a wave inserts and the lists the last block folds, the filtered search behind short_scan_kernel stays flat.
+    // $ISE_DIRECT_SHORT_MAX_TILES moves the crossover.
     int max_tiles = knobs().direct_short_max_tiles.load(std::memory_order_relaxed);
-    if (max_tiles <= 0) max_tiles = 256;
+    if (max_tiles <= 0) max_tiles = 128;
     if (pl.short_ && pl.tiles_total > max_tiles) return false;
     // rows per block: ~32 KB worth, between 16 (one step per wave) and 64 (4 waves x XR rows x 4 steps), and fewer
     // than 64 only as far as it takes to put a small index on 64 blocks: the scan of a block is latency-bound, so a

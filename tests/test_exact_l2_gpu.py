@@ -61,7 +61,7 @@ def forced_exact():
 
 def force_direct():
     """One-query float32 L2 batches run the direct-difference scan whatever the index length (by default indexes
-    between ~4k and 262k rows take the filtered path behind the short-index scan kernel instead)."""
+    between ~2k and 262k rows take the filtered path behind the short-index scan kernel instead)."""
     return env_knob("ISE_DIRECT_SHORT_MAX_TILES", 1 << 30)
 
 
@@ -112,7 +112,7 @@ def test_l2_exact_on_adversarial_data(faiss, kind, nq, adds):
     D_ref, I_ref = ko.knn_exact(xb, xq, k, L2)
     n_mism = assert_knn_matches(D, I, D_ref, I_ref, xb, xq, L2, gap=ko.kth_gap(xb, xq, k, L2))
     assert n_mism == 0 or kind == "two_far_clusters"  # only float32 near-ties may differ, and only there
-    # (the search between the adds met 5000 rows: above the direct scan's 256 row tiles, so the short kernel as well)
+    # (the search between the adds met 5000 rows: above the direct scan's 128 row tiles, so the short kernel as well)
     assert index.short_stats() == {"short_batches": 2 if adds == "several" else 1}
     if nq == 1:  # a one-query batch through the direct scan alone and through the streaming kernels: the same bits
         with force_direct():

@@ -407,9 +407,10 @@ def test_config2_cnn_embeddings_to_l2_index_end_to_end():
     D0, I0 = index.search(xb[17:18], 1)
     assert I0[0, 0] == 17 and D0[0, 0] == 0.0
     st = index.exact_stats()
-    # the batch of nq queries was scanned by the short-index kernel, the one-query batch (3000 rows) by the direct scan
-    assert st["reranked"] == nq and index.short_stats() == {"short_batches": 1}
-    assert index.host_stats()["direct_queries"] == 1
+    # both batches were scanned by the short-index kernel and re-ranked (3000 rows: above the one-query direct
+    # scan's 128 row tiles)
+    assert st["reranked"] == nq + 1 and index.short_stats() == {"short_batches": 2}
+    assert index.host_stats()["direct_queries"] == 0
 
 
 def test_config2_at_full_size():

@@ -69,8 +69,8 @@ def test_short_kernel_equals_the_streaming_path_and_the_oracle(faiss, metric, st
     launched = index.short_stats()["short_batches"]
     for nq, k in ((1, 10), (5, 1), (16, 10), (16, kmax), (7, 3)):
         xq, xq_r = xq_all[:nq], xq_r_all[:nq]
-        # one float32 L2 query against an index of up to 256 row tiles is answered by the direct scan (one launch)
-        short = not (nq == 1 and metric == L2 and storage == "f32" and (n + 15) // 16 <= 256)
+        # one float32 L2 query against an index of up to 128 row tiles is answered by the direct scan (one launch)
+        short = not (nq == 1 and metric == L2 and storage == "f32" and (n + 15) // 16 <= 128)
         D, I = index.search(xq, k)
         launched += 1 if short else 0
         assert index.short_stats() == {"short_batches": launched}, (nq, k)
