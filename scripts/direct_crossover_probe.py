@@ -5,10 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_search_engine_amd.faiss_compat as faiss
 from image_search_engine_amd import _native as n
 torch.manual_seed(5)
+LAT = os.environ.get("LATENCY", "0") == "1"   # 1: synchronise after every call (one caller at a time) instead of back to back
 def timed(index, xq, k, reps=400):
     for _ in range(50): index.search_torch(xq, k)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps): index.search_torch(xq, k)
+    for _ in range(reps):
+        index.search_torch(xq, k)
+        if LAT: torch.cuda.synchronize()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e6
 warm = faiss.IndexFlatL2(512); warm.add_torch(torch.rand((100_000, 512), device="cuda"))
 timed(warm, torch.rand((16, 512), device="cuda"), 10, 20000)
