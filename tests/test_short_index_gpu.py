@@ -218,3 +218,31 @@ def test_config2_and_shard_sizes_at_full_size(faiss):
             assert_knn_matches(D, I, Dc[:nq], Ic[:nq], xb[:n], xq[:nq], 1, atol=ATOL_UNIFORM)
         assert index.short_stats() == {"short_batches": 2}
         assert index.exact_stats()["exact_scan"] == 0
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("n,d", [(1000, 2048), (4000, 2048), (1000, 1024), (999, 2047), (1000, 512), (5000, 500), (37, 2048)])
+def test_small_indexes_spread_over_the_cus(faiss, metric, n, d):
+    """The reference's own index size (about 1000 descriptors of 2048 floats, backend/utils.py:309-310,
+    backend/descriptors.py:120) and its neighbours: the plans spread so small an index over the CUs -- single
+    row tiles per block for rows of more than 2 KB, ~64 KB of rows per block otherwise (make_plan, the short-index
+    plan, the one-query direct scan) -- and the results are the oracle's for batches of 1, 16, 17, 33 and 64
+    queries (one and several query tiles per pass, one and several passes), through the host entry point and,
+    packed as keys with global ids, through the shard entry point."""
+    import torch
+
+    rng = np.random.default_rng(n * 7 + d + metric)
+    xb, xq_all = _data(rng, n, d, 64, unit=(metric == IP))
+    index = faiss.IndexFlat(d, metric)
+    index.add(xb)
+    for nq, k in ((1, 20), (16, 10), (17, 10), (33, 5), (64, 20), (1, 1)):
+        xq = xq_all[:nq]
+        D, I = index.search(xq, k)
+        D_ref, I_ref = ko.knn_exact(xb, xq, k, metric)
+        assert_knn_matches(D, I, D_ref, I_ref, xb, xq, metric, gap=ko.kth_gap(xb, xq, k, metric) if n > k else None)
+        keys = index.search_keys_torch(torch.from_numpy(xq).cuda(), k, 777)
+        Dm, Im = faiss.merge_keys_torch(keys[None], metric)
+        assert np.array_equal(Im.cpu().numpy(), np.where(I >= 0, I + 777, -1)) and np.array_equal(Dm.cpu().numpy(), D)
+    # a row queried against itself comes back first (L2: at distance exactly 0)
+    D0, I0 = index.search(xb[n // 2:n // 2 + 1], 1)
+    assert I0[0, 0] == n // 2 and (metric == IP or D0[0, 0] == 0.0)
