@@ -706,7 +706,12 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
     // Short indexes, one query tile, one pass: short_scan_kernel (scores dumped to LDS, one selection per block;
     // ise_short_scan.hpp) writes the per-block lists instead of scan_kernel.  Two 8-wave blocks per CU when their
     // LDS images fit side by side, else one; a block's rows must fit the selection (SHORT_TPB_MAX tiles).
-    if (allow_short && nq <= 16 && pl->kc <= pl->kpass && h->n > 0 && !knobs().no_short.load(std::memory_order_relaxed)) {
+    // 17 .. 64 queries: the same kernel with TWO query tiles per pass (twice the MFMA work per row tile, still under
+    // the row stream for float32 at d = 512), 33 .. 64 as two such passes side by side (grid.y)
+    static const bool short_t2 = [] { const char* e = getenv("ISE_SHORT_T2"); return !(e && e[0] == '0'); }();
+    const int short_T = nq <= 16 ? 1 : 2;
+    if (allow_short && (nq <= 16 || (short_t2 && nq <= 64)) && pl->kc <= pl->kpass && h->n > 0 &&
+        !knobs().no_short.load(std::memory_order_relaxed)) {
         int tpb_max = knobs().short_tpb_max.load(std::memory_order_relaxed);
         if (tpb_max <= 0 || tpb_max > SHORT_TPB_MAX) tpb_max = SHORT_TPB_MAX;
         const int S = qs_stride_for(h);
@@ -725,12 +730,14 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
 #endif
         for (int si = first; si < 2 && !pl->short_; si++) {
             const int wv = shapes[si][0], bpc = shapes[si][1];
+            const int short_nqt = (int)((nq + 16 * short_T - 1) / (16 * short_T));
             const int packed = (pl->tiles_total + wv - 1) / wv;
-            const int spread = (pl->tiles_total + min_tiles - 1) / min_tiles;  // as above: >= ~64 KB of rows per block
+            // as above: >= ~64 KB of rows per block, the whole launch resident at once
+            const int spread = std::min(std::max(1, h->num_cu * bpc / short_nqt), (pl->tiles_total + min_tiles - 1) / min_tiles);
             int nbs = std::max(1, std::min(h->num_cu * bpc * shapes[si][2], std::max(packed, spread)));
             nbs = std::min(nbs, MERGE_LISTS_MAX);
             const int tpb = (pl->tiles_total + nbs - 1) / nbs;
-            const size_t lds = short_lds_layout(S, tpb, wv);
+            const size_t lds = short_lds_layout(S, tpb, wv, short_T);
             if (tpb <= tpb_max && lds <= (size_t)LDS_LIMIT / bpc) {
                 pl->short_ = true;
                 pl->nblocks = nbs;
@@ -738,8 +745,8 @@ static int make_plan(const ise_index* h, long long nq, int k, ScanPlan* pl, bool
                 pl->lds = lds;
                 pl->waves = wv;
                 pl->short_bpc = bpc;
-                pl->T = 1;
-                pl->nqt = 1;
+                pl->T = short_T;
+                pl->nqt = short_nqt;
                 pl->ch = std::min(chunk_steps(h), 4);
             }
         }
@@ -1181,6 +1188,8 @@ static int scan_path_enqueue(ise_index* h, ise_index::WorkSlot* w, const ScanPla
         if (gate) return fail(ISE_E_INVALID, "internal: a gated rerun was planned for the short-index kernel");
         ShortParams shp;
         shp.even_split = 1;
+        shp.T = pl.T;
+        shp.nqt = pl.nqt;
         h->short_batches++;
         if (tm && tm->on) HIP_TRY(hipEventRecord(tm->e0, st));
         launch_short(h, pl.ch, pl.waves, pl.short_bpc, pl.nblocks, pl.lds, st, sp, shp);

@@ -67,7 +67,10 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     // for short indexes, where the exchange would not run anyway) nor at T = 1 (neutral).
     constexpr bool XCHG = T >= 3 || (T == 2 && W == 8);
     constexpr int NQ = 16 * T;                        // queries per block pass
-    constexpr int TPR = BLOCK_THREADS / 16;           // threads staging one query row (per tile)
+    // threads staging one query row (per tile).  16-wave blocks stage with their first 8 waves: |x|^2 then has the
+    // summation order of the 8-wave kernels (and of short_scan_kernel), and the bf16 L2 distances, which carry it,
+    // come out the same bits whichever kernel scans (4-wave blocks exist for rows no other kernel takes)
+    constexpr int TPR = W >= 16 ? 32 : BLOCK_THREADS / 16;
     constexpr int KPLB = (W * 16 + 63) / 64;          // boot: keys per lane
     constexpr int KPLF = (KB_MAX + W * CAP + 63) / 64;  // final: keys per lane (worst case)
     static_assert(KB_MAX + CAP <= 64 && MERGE_TRIG + 4 <= CAP, "list sizes");
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
                        S4 <= TPR * QVS;
     f32x4 qv[T][QV];
     f32x4 muv[SHIFT ? QVS : 1];
-    if (SHIFT && vec_q) {
+    const bool stager = tid < 16 * TPR;  // whole waves
+    if (SHIFT && vec_q && stager) {
 #pragma unroll
         for (int i = 0; i < QVS; i++) {
             const int j4 = tid % TPR + i * TPR;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
             if (j4 < dslots) muv[i] = *reinterpret_cast<const f32x4*>(p.mu + 4 * j4);
         }
     }
-    if (vec_q) {
+    if (vec_q && stager) {
 #pragma unroll
         for (int tq = 0; tq < T; tq++) {
             const int cc = tq * 16 + tid / TPR, t = tid % TPR;
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(W * 64, T == 1 ? W / 2 : (W / 4 > 0 ? W / 4 : 1)) v
     auto bf16_round = [](float v) -> float { return (float)(__bf16)v; };
 #pragma unroll
     for (int tq = 0; tq < T; tq++) {
+        if (!stager) continue;
         const int cc = tq * 16 + tid / TPR, t = tid % TPR;
         float sn = 0.f;
         if (vec_q) {

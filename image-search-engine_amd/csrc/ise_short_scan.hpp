@@ -34,14 +34,17 @@
 
 struct ShortParams {
     int even_split;  // 1 = the row tiles are split evenly over the blocks instead of tiles_per_block each
+    int T = 1;       // query tiles per pass (1 or 2)
+    int nqt = 1;     // passes side by side (grid.y): ceil(nq / (16 T))
 };
 
 // dump row stride in floats: whole 32-float groups + 4, so that the 8 lanes of a 16-byte store group
 // (8 queries, same rows) fall into different banks
 __host__ __device__ constexpr int short_dump_stride(int tiles_per_block) { return (tiles_per_block * 16 + 31) / 32 * 32 + 4; }
-__host__ __device__ constexpr size_t short_lds_layout(int S, int tiles_per_block, int waves) {
-    const size_t head = (size_t)S * 4 + 16 * ((size_t)S * 4) + 16 * 4;  // mus | qs | xn
-    const size_t dump = (size_t)16 * short_dump_stride(tiles_per_block) * 4 + (size_t)waves * 64 * 8;  // + selection scratch
+__host__ __device__ constexpr size_t short_lds_layout(int S, int tiles_per_block, int waves, int T = 1) {
+    const size_t nq = (size_t)16 * T;
+    const size_t head = (size_t)S * 4 + nq * ((size_t)S * 4) + nq * 4;  // mus | qs | xn
+    const size_t dump = nq * short_dump_stride(tiles_per_block) * 4 + (size_t)waves * 64 * 8;  // + selection scratch
     return head + dump;
 }
 
@@ -62,10 +65,12 @@ __host__ __device__ constexpr size_t short_lds_layout(int S, int tiles_per_block
 
 // CH: k-steps per register chunk; R: chunks in the ring (R - 1 requested ahead of the one computed)
 // WPS: waves per SIMD the register budget is sized for (blocks per CU * W / 4)
-template <int CH, int R, int W, int WPS, bool BF16, bool SHIFT>
+// T: 16-query tiles scored per pass over the rows (1: batches of up to 16 queries; 2: of 17 .. 32, and 33 .. 64 as
+//    two such passes side by side in grid.y) -- the same MFMA tile per query tile, the same bits
+template <int CH, int R, int W, int WPS, int T, bool BF16, bool SHIFT>
 __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParams p, const ShortParams tp) {
     static_assert(!(BF16 && SHIFT), "the shift is applied to fp32 rows only");
-    constexpr int NQ = 16;
+    constexpr int NQ = 16 * T;
     // 32 threads stage one query row, whatever the block width (a 16-wave block stages with its first 8 waves):
     // the sum of squares |x|^2 then has ONE summation order -- the one of scan_kernel's 8-wave blocks -- and
     // the bf16 L2 distances, which carry it, come out the same bits from every kernel
@@ -83,7 +88,8 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool stager = tid < 16 * TPR;
     const int c = lane & 15, g = lane >> 4;
-    const int nqt = min(NQ, p.nq);
+    const int q0 = blockIdx.y * NQ;  // this block's first query
+    const int nqt = min(NQ, p.nq - q0);
     const int k = p.k;
     const int nsteps = p.row_slots >> 2;
     // a block owns tiles_per_block = 8 r consecutive row tiles, its waves interleave: r tiles per wave, every
@@ -118,15 +124,15 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
                        S4 <= TPR * QVS;
     f32x4 qv[QV];
     f32x4 mu1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (stager) {
-        const int cc = tid / TPR, t = tid % TPR;
-        const bool rowok = cc < nqt;
-        const float* src = p.q + (size_t)(rowok ? cc : 0) * p.d;
-        // the shift vector goes through LDS (one slot per thread, S4 <= 256 here) and the queries read it from
-        // there: held in registers per thread (8 slots) it would cost the ring a chunk.  Requested first: waits
-        // are counted in issue order
-        if (SHIFT && vec_q && tid < dslots) mu1 = *reinterpret_cast<const f32x4*>(p.mu + 4 * tid);
-        if (vec_q) {
+    // the shift vector goes through LDS (one slot per thread, S4 <= 256 here) and the queries read it from
+    // there: held in registers per thread (8 slots) it would cost the ring a chunk.  Requested first: waits
+    // are counted in issue order
+    if (stager && SHIFT && vec_q && tid < dslots) mu1 = *reinterpret_cast<const f32x4*>(p.mu + 4 * tid);
+    auto request_queries = [&](int tq) {  // step 1 for query tile tq: TPR threads per row, QV 16-byte pieces each
+        if (stager && vec_q) {
+            const int cc = tq * 16 + tid / TPR, t = tid % TPR;
+            const bool rowok = cc < nqt;
+            const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
 #pragma unroll
             for (int i = 0; i < QVS; i++) {
                 const int j4 = t + i * TPR;
@@ -137,7 +143,8 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
                 }
             }
         }
-    }
+    };
+    request_queries(0);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- the ring: R - 1 chunks requested now, so the row stream runs while the queries are staged
@@ -168,8 +175,9 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
         return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
     };
     auto bf16_round = [](float v) -> float { return (float)(__bf16)v; };
-    if (stager) {
-        const int cc = tid / TPR, t = tid % TPR;
+    auto store_queries = [&](int tq) {
+      if (stager) {
+        const int cc = tq * 16 + tid / TPR, t = tid % TPR;
         float sn = 0.f;
         if (vec_q) {
 #pragma unroll
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
             }
         } else {  // odd d, unaligned queries or very long rows: one 4-byte unit at a time
             const bool rowok = cc < nqt;
-            const float* src = p.q + (size_t)(rowok ? cc : 0) * p.d;
+            const float* src = p.q + (size_t)(q0 + (rowok ? cc : 0)) * p.d;
             for (int j = t; j < S; j += TPR) {
                 if (BF16) {
                     const float lo = (rowok && 2 * j < p.d) ? src[2 * j] : 0.f;
@@ -224,47 +232,66 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
 #pragma unroll
         for (int o = TPR / 2; o > 0; o >>= 1) sn += __shfl_xor(sn, o);
         if (t == 0) xn[cc] = sn;
+      }
+    };
+    store_queries(0);
+#pragma unroll
+    for (int tq = 1; tq < T; tq++) {  // further query tiles: behind the first, the row stream already running
+        request_queries(tq);
+        store_queries(tq);
     }
     __syncthreads();
     SSTAMP(1);
 
     // ---- the row tiles of this wave, back to back.  Scores exactly as scan_kernel keys them (ise_scan.hpp).
-    const float* qrow = qs + c * S + 4 * g;
-    const float xq_n = xn[c];
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto score = [&](float dotj, float ynj) -> float {
+    const float* qrow = qs + c * S + 4 * g;  // query tile t: + t * 16 * S
+    float xq_n[T];
+    f32x4 acc0[T], acc1[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        xq_n[t] = xn[t * 16 + c];
+        acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto score = [&](float dotj, float ynj, float xqn) -> float {
         if (l2) {
-            const float tt = xq_n + ynj;
+            const float tt = xqn + ynj;
             const float sc = tt - 2.f * dotj;
             if (SHIFT) return fmaf(-p.beta, tt, sc);
             return sc < 0.f ? 0.f : sc;  // keeps NaN (Faiss: if (dis < 0) dis = 0)
         }
         return -dotj;
     };
-    f32x4 bcur;
-    auto load_b = [&](f32x4& b, int step) { b = *reinterpret_cast<const f32x4*>(qrow + 16 * step); };
+    f32x4 bcur[T];
+    auto load_b = [&](f32x4(&b)[T], int step) {
+#pragma unroll
+        for (int t = 0; t < T; t++) b[t] = *reinterpret_cast<const f32x4*>(qrow + (size_t)t * 16 * S + 16 * step);
+    };
     auto compute_chunk = [&](const f32x4(&a)[CH], int s0, int next_first_step) {
 #pragma unroll
         for (int s = 0; s < CH; s++) {
             if (SABL(64)) {  // dev: no LDS reads, no MFMA -- the loaded data is only summed
-                acc0 += a[s];
+                acc0[0] += a[s];
                 continue;
             }
-            f32x4 bnext;
+            f32x4 bnext[T];
             load_b(bnext, s + 1 < CH ? s0 + s + 1 : next_first_step);
             f32x4 as = a[s];
             if (SHIFT) as = as - *reinterpret_cast<const f32x4*>(mus + 4 * g + 16 * (s0 + s));
-            if (BF16) {
-                const bf16x8 av = __builtin_bit_cast(bf16x8, a[s]), bv = __builtin_bit_cast(bf16x8, bcur);
-                if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc0, 0, 0, 0);
-            } else {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[0], bcur[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[1], bcur[1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[2], bcur[2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[3], bcur[3], acc1, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                if (BF16) {
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, a[s]), bv = __builtin_bit_cast(bf16x8, bcur[t]);
+                    if (s & 1) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc1[t], 0, 0, 0);
+                    else acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc0[t], 0, 0, 0);
+                } else {
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[0], bcur[t][0], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[1], bcur[t][1], acc1[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[2], bcur[t][2], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[3], bcur[t][3], acc1[t], 0, 0, 0);
+                }
+                bcur[t] = bnext[t];
             }
-            bcur = bnext;
         }
     };
     if (has_work) {
@@ -282,20 +309,23 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
                     int ns0 = s0 + CH, ntile = tile;
                     if (ns0 >= nsteps) { ns0 = 0; ntile = tile + W; }
                     compute_chunk(A[j], s0, ns0);
-                    if (ns0 == 0) {  // the tile is complete: its 16 x 16 scores go to the dump
-                        const f32x4 dot = acc0 + acc1;
-                        acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        // rows past the end of the index and scores that may not enter (>= FLT_MAX, NaN: Faiss's
-                        // strict gate) are dumped as +inf: the selection then compares plain floats
-                        f32x4 sc;
+                    if (ns0 == 0) {  // the tile is complete: its 16 x 16 scores per query tile go to the dump
                         const long long row0 = (long long)tile * 16 + 4 * g;
 #pragma unroll
-                        for (int jj = 0; jj < 4; jj++) {
-                            const float v = score(dot[jj], yn[jj]);
-                            sc[jj] = (row0 + jj < p.n && v < FLT_MAX) ? v : __builtin_inff();
+                        for (int t = 0; t < T; t++) {
+                            const f32x4 dot = acc0[t] + acc1[t];
+                            acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            // rows past the end of the index and scores that may not enter (>= FLT_MAX, NaN: Faiss's
+                            // strict gate) are dumped as +inf: the selection then compares plain floats
+                            f32x4 sc;
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const float v = score(dot[jj], yn[jj], xq_n[t]);
+                                sc[jj] = (row0 + jj < p.n && v < FLT_MAX) ? v : __builtin_inff();
+                            }
+                            *reinterpret_cast<f32x4*>(dump + (size_t)(t * 16 + c) * DS + (tile - t0) * 16 + 4 * g) = sc;
                         }
-                        *reinterpret_cast<f32x4*>(dump + (size_t)c * DS + (tile - t0) * 16 + 4 * g) = sc;
                         if (tile == t0 + w) SSTAMP(8);
                     }
                     done = ntile >= t1;
@@ -322,7 +352,7 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
     const u64 lt_mask = (1ull << lane) - 1ull;
     const float INF = __builtin_inff();
     for (int qq = w; qq < NQ && !SABL(4); qq += W) {
-        u64* out = p.part + ((size_t)blockIdx.x * NQ + qq) * k;
+        u64* out = p.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NQ + qq) * k;
         if (qq >= nqt) {  // a padding query of the tile: an empty list (the merge never reads it)
             if (lane < k) out[lane] = KEY_PAD;
             continue;
@@ -339,14 +369,14 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
             }
         }
         if (qq == w) SSTAMP(9);
-        // T = the k-th smallest lane minimum (by value); fewer than k lanes with a row: every row stays
-        float T = FLT_MAX;
+        // TH = the k-th smallest lane minimum (by value); fewer than k lanes with a row: every row stays
+        float TH = FLT_MAX;
         if (__popcll(__ballot(mn < INF)) >= k) {
             float L = -INF, H = INF;  // the target lies in [L, H]; lanes strictly inside are pivot candidates
             for (int round = 0;; round++) {
                 const u64 m = __ballot(mn > L && mn < H);
                 if (!m) {  // nothing strictly inside: the target is one of the bounds
-                    T = __popcll(__ballot(mn <= L)) >= k ? L : H;
+                    TH = __popcll(__ballot(mn <= L)) >= k ? L : H;
                     break;
                 }
                 const int rot = (round * 23 + 7) & 63;
@@ -355,7 +385,7 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
                                                                                     __ffsll((long long)(hi ? hi : m)) - 1));
                 const int c_lt = __popcll(__ballot(mn < P)), c_le = __popcll(__ballot(mn <= P));
                 if (c_lt < k && c_le >= k) {
-                    T = P;
+                    TH = P;
                     break;
                 }
                 if (c_lt >= k) H = P;
@@ -367,7 +397,7 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
 #pragma unroll
         for (int e = 0; e < SHORT_KPL; e++) {
             if (e < ne) {
-                const bool keep = v[e] <= T;  // +inf (no row) never: T <= FLT_MAX
+                const bool keep = v[e] <= TH;  // +inf (no row) never: TH <= FLT_MAX
                 const u64 m = __ballot(keep);
                 const int pos = cnt + __popcll(m & lt_mask);
                 if (keep && pos < 64)
@@ -409,9 +439,15 @@ __global__ __launch_bounds__(W * 64, WPS) void short_scan_kernel(const ScanParam
 
 template <int CH, int R, int W, int WPS, bool BF16, bool SHIFT>
 static void launch_short_r(int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp) {
+    if (tp.T == 2) {  // 17 .. 64 queries: two query tiles per pass, grid.y passes side by side
+        static LdsAttrOnce attr2;
+        attr2.ensure(reinterpret_cast<const void*>(&short_scan_kernel<CH, R, W, WPS, 2, BF16, SHIFT>), LDS_LIMIT);
+        hipLaunchKernelGGL((short_scan_kernel<CH, R, W, WPS, 2, BF16, SHIFT>), dim3(grid, tp.nqt), dim3(W * 64), lds, st, sp, tp);
+        return;
+    }
     static LdsAttrOnce attr;
-    attr.ensure(reinterpret_cast<const void*>(&short_scan_kernel<CH, R, W, WPS, BF16, SHIFT>), LDS_LIMIT);
-    hipLaunchKernelGGL((short_scan_kernel<CH, R, W, WPS, BF16, SHIFT>), dim3(grid), dim3(W * 64), lds, st, sp, tp);
+    attr.ensure(reinterpret_cast<const void*>(&short_scan_kernel<CH, R, W, WPS, 1, BF16, SHIFT>), LDS_LIMIT);
+    hipLaunchKernelGGL((short_scan_kernel<CH, R, W, WPS, 1, BF16, SHIFT>), dim3(grid), dim3(W * 64), lds, st, sp, tp);
 }
 template <int CH, int W, int WPS, bool BF16, bool SHIFT>
 static void launch_short_one(int grid, size_t lds, hipStream_t st, const ScanParams& sp, const ShortParams& tp) {

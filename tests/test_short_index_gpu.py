@@ -54,20 +54,21 @@ SHAPES = [  # n, d: block counts from 1 to the full grid, tails in rows and in c
 @pytest.mark.parametrize("n,d", SHAPES)
 def test_short_kernel_equals_the_streaming_path_and_the_oracle(faiss, metric, storage, n, d):
     """Every instantiation (float32 L2 in front of the exact re-rank, float32 inner product, bf16 rows), batches
-    of 1, 5 and 16 queries, k = 1, 10 and the largest one pass takes, through the host entry point and the packed
+    of 1 to 64 queries (one and two query tiles per pass), k = 1, 10 and the largest one pass takes, through the host entry point and the packed
     keys of the shard entry point (global ids): short-index kernel == streaming kernel, bit for bit, and both
     match the oracle (bf16: on the rounded values the index holds)."""
     import torch
 
     rng = np.random.default_rng(n * 31 + d + metric)
-    nq_max = 16
+    nq_max = 64
     xb, xq_all = _data(rng, n, d, nq_max, unit=(metric == IP))
     index = faiss.IndexFlat(d, metric, storage=storage)
     index.add(xb)
     xb_r, xq_r_all = (xb, xq_all) if storage == "f32" else (_bf16_round(xb), _bf16_round(xq_all))
     kmax = 28 if (metric == L2 and storage == "f32") else 32   # float32 L2 keeps 4 spare candidates per query
     launched = index.short_stats()["short_batches"]
-    for nq, k in ((1, 10), (5, 1), (16, 10), (16, kmax), (7, 3)):
+    # 17 .. 64 queries: two query tiles per pass (33 .. 64: two passes side by side in one launch)
+    for nq, k in ((1, 10), (5, 1), (16, 10), (16, kmax), (7, 3), (17, 10), (32, kmax), (33, 5), (64, 10)):
         xq, xq_r = xq_all[:nq], xq_r_all[:nq]
         # one float32 L2 query against an index of up to 128 row tiles is answered by the direct scan (one launch)
         short = not (nq == 1 and metric == L2 and storage == "f32" and (n + 15) // 16 <= 128)
@@ -87,13 +88,14 @@ def test_short_kernel_equals_the_streaming_path_and_the_oracle(faiss, metric, st
 
 
 def test_what_does_not_take_the_short_kernel(faiss):
-    """17 queries (two query tiles), k whose candidates need two passes, an index with more than 32 row tiles
-    per block and rows of more than 2 KB keep the streaming kernels; the answers still agree with the oracle."""
+    """65 queries (more than two passes of two query tiles), k whose candidates need two passes, an index with more
+    than 32 row tiles per block and rows of more than 2 KB keep the streaming kernels; the answers still agree
+    with the oracle."""
     rng = np.random.default_rng(8)
-    xb, xq = _data(rng, 50_000, 64, 17, unit=False)
+    xb, xq = _data(rng, 50_000, 64, 65, unit=False)
     index = faiss.IndexFlatL2(64)
     index.add(xb)
-    for nq, k in ((17, 10), (4, 33), (16, 100)):
+    for nq, k in ((65, 10), (4, 33), (16, 100)):
         D, I = index.search(xq[:nq], k)
         D_ref, I_ref = ko.knn_exact(xb, xq[:nq], k, L2)
         assert_knn_matches(D, I, D_ref, I_ref, xb, xq[:nq], L2, gap=ko.kth_gap(xb, xq[:nq], k, L2), atol=ATOL_UNIFORM)
