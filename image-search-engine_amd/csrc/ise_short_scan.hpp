@@ -1,4 +1,4 @@
-// ise_short_scan.hpp -- the scan of one batch of <= 16 queries against a SHORT index.
+// ise_short_scan.hpp -- the scan of one batch of <= 64 queries (one or two 16-query tiles per pass) against a SHORT index.
 //
 // The reference's own regime is short indexes (about 1 k images, backend/utils.py:309-310; one query per
 // request, backend/engine.py:50-55); BASELINE config 2 is 100k x 512 and every rank of the 8-GPU run scans a
