@@ -62,6 +62,8 @@ __global__ __launch_bounds__(256, QN == 1 ? 2 : 4) void exact_scan_kernel(const 
     const bool direct = p.direct_n > 0;
     __shared__ u64 wmin[2][4];
     __shared__ int is_last;
+    __shared__ u64 fold_stage[4 * 32];  // the last block's selection scratch (block_topk_u64) and its result
+    __shared__ u64 fold_out[32];
     extern __shared__ __align__(16) unsigned char smem_xs[];
     float* qs = reinterpret_cast<float*>(smem_xs);            // [QN][dp]
     u64* wl = reinterpret_cast<u64*>(qs + (size_t)QN * p.dp);  // [QN][4 waves][32]
@@ -205,10 +207,19 @@ __global__ __launch_bounds__(256, QN == 1 ? 2 : 4) void exact_scan_kernel(const 
     }
     __syncthreads();
     if (!is_last) return;
+    // Up to 4096 keys in all (a small index: the reference's own ~1000 rows give 63 lists of k = 20): the lists
+    // are contiguous, [blocks][kp] -- one quickselect over all of them (two barriers) instead of kp block-wide
+    // argmin rounds of ~1 us each (1000 x 2048, k = 20: the call's device time 33 -> see DESIGN.md 4.2-5)
+    const bool small_fold = (long long)gridDim.x * kp <= 4096 && mp.stride_list == kp && kp <= 32;
     for (int i = 0; i < nfl; i++) {
         const u64* base = mp.lists + (size_t)i * mp.stride_qtile;
         const int q = (mp.out_by_pos || direct) ? i : p.fl_list[i];
-        merge_rounds<256, 4>(mp, base, wmin, [&](int r, u64 key) { emit_result(mp, (size_t)q * kp + r, key); });
+        if (small_fold) {
+            block_topk_u64(base, (int)gridDim.x * kp, kp, fold_stage, fold_out);
+            if (tid < kp) emit_result(mp, (size_t)q * kp + tid, fold_out[tid]);
+        } else {
+            merge_rounds<256, 4>(mp, base, wmin, [&](int r, u64 key) { emit_result(mp, (size_t)q * kp + r, key); });
+        }
         __syncthreads();
     }
 }
