@@ -95,3 +95,41 @@ def test_kernel_source_hash_follows_the_sources(tmp_path, monkeypatch):
     assert h1 != h0
     (tmp_path / "include" / "ise_knn.h").write_text("z2")
     assert bench.kernel_source_hash() not in (h0, h1)
+
+
+def test_pmc_reduction_calibrates_reads_on_the_known_copy(tmp_path):
+    """scripts/pmc_to_json.py on synthetic counter files: FETCH_SIZE is reported in KB and, on gfx950, at half
+    the bytes of a wide read -- the device-to-device copy of the index in the same trace (known byte count) gives
+    the ratio the scan's reads are divided by; WRITE_SIZE is taken as it is."""
+    n, nq, d, k = 1000, 16, 512, 10
+    known = 4.0 * n * d
+    alg = known + 4.0 * nq * d + 12.0 * nq * k
+    kname = "void short_scan_kernel<4, 2, 16, 4, 1, false, true>(ScanParams, ShortParams)"
+
+    def counter_file(sub, counter, rows):
+        p = tmp_path / "prof" / sub / "runc"
+        p.mkdir(parents=True)
+        with open(p / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            for name, v in rows:
+                w.writerow([name, counter, v])
+
+    half = 0.5
+    counter_file("pmc_fetch", "FETCH_SIZE",
+                 [("__amd_rocclr_copyBuffer", 3.0), ("__amd_rocclr_copyBuffer", known * half / 1024.0)] +
+                 [(kname, 1.01 * alg * half / 1024.0)] * 5 + [("void merge_kernel<true>(M, E)", 7.0)] * 5)
+    counter_file("pmc_write", "WRITE_SIZE", [(kname, 2.0)] * 5 + [("__amd_rocclr_copyBuffer", known / 1024.0)])
+    out = tmp_path / "rec" / "bench_n1000_nq16_hbm_pmc.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_to_json.py"), str(tmp_path / "prof"), str(out),
+                        str(n), str(nq), "void short_scan_kernel"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(out.read_text())
+    assert abs(rec["calibration"]["ratio"] - half) < 1e-12
+    sk = rec["scan_kernel"]
+    assert abs(sk["fetch_bytes_per_launch_corrected"] - 1.01 * alg) < 1e-3 and sk["write_bytes_per_launch"] == 2048.0
+    assert abs(sk["algorithmic_bytes_per_launch"] - alg) < 1e-9
+    assert abs(sk["traffic_over_algorithmic"] - (1.01 * alg + 2048.0) / alg) < 1e-9
+    import bench
+
+    assert rec["kernel"] == kname and rec["kernel_source_hash"] == bench.kernel_source_hash()
