@@ -88,3 +88,21 @@ def test_comm_entry_points_without_a_gpu():
     if not torch.cuda.is_available() and rc == 0:
         assert n.lib.ise_comm_create(ctypes.byref(h), buf.raw, 1, 0, 0) == n.E_NODEVICE
         assert b"GPU" in n.lib.ise_last_error()
+
+
+def test_header_is_plain_c():
+    """include/ise_knn.h is the drop-in boundary: it must compile as C99 on its own (plain pointers and sizes,
+    no C++ or torch types), and as C++ behind its extern "C" guard."""
+    import shutil
+    import subprocess
+
+    hdr = os.path.join(ROOT, "include", "ise_knn.h")
+    gcc, gxx = shutil.which("gcc"), shutil.which("g++")
+    if not gcc or not gxx:
+        pytest.skip("no host C/C++ compiler")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([gxx, "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", hdr],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
