@@ -219,3 +219,69 @@ def test_make_golden_check_reproduces_every_committed_fixture(golden_dir):
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
     assert mg.check(verbose=False) == []
+
+
+def test_c_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """The C restatement (oracle/flat_oracle.c) is the checker of every GPU parity test: a driver runs its entry
+    points over ragged shapes (d not a multiple of 8, k larger than the index, an empty index, one row, ties,
+    several OpenMP threads) in a build with AddressSanitizer and UndefinedBehaviorSanitizer; any report fails."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no host C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = tmp_path / "driver.c"
+    drv.write_text(r'''
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <float.h>
+int oracle_knn_flat(const float*, int64_t, int, const float*, int64_t, int, int, float*, int64_t*, int);
+void oracle_renorm_L2(size_t, size_t, float*);
+float oracle_fvec_L2sqr(const float*, const float*, size_t);
+float oracle_fvec_inner_product(const float*, const float*, size_t);
+static unsigned s = 12345u;
+static float rnd(void) { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.0f; }
+int main(void) {
+    const int shapes[][4] = {{0, 5, 3, 4}, {1, 1, 1, 1}, {1, 7, 2, 5}, {17, 3, 4, 20}, {100, 13, 5, 10},
+                             {257, 64, 16, 7}, {1000, 37, 3, 1}, {64, 8, 64, 64}, {33, 100, 1, 40}};
+    for (unsigned c = 0; c < sizeof(shapes) / sizeof(shapes[0]); c++) {
+        const int n = shapes[c][0], d = shapes[c][1], nq = shapes[c][2], k = shapes[c][3];
+        float* xb = malloc(sizeof(float) * (size_t)(n > 0 ? n : 1) * d);
+        float* xq = malloc(sizeof(float) * (size_t)nq * d);
+        float* D = malloc(sizeof(float) * (size_t)nq * k);
+        int64_t* I = malloc(sizeof(int64_t) * (size_t)nq * k);
+        for (int i = 0; i < n * d; i++) xb[i] = rnd();
+        for (int i = 0; i < nq * d; i++) xq[i] = rnd();
+        if (n > 3) for (int j = 0; j < d; j++) xb[(n - 1) * d + j] = xb[j];  /* a duplicate row: a tie */
+        for (int metric = 0; metric <= 1; metric++)
+            for (int nt = 1; nt <= 3; nt += 2) {
+                oracle_knn_flat(xb, n, d, xq, nq, k, metric, D, I, nt);
+                for (int q = 0; q < nq; q++)
+                    for (int r = 0; r < k; r++) {
+                        const int64_t id = I[q * k + r];
+                        if (r < n ? (id < 0 || id >= n) : id != -1) { printf("bad id %d %d\n", c, r); return 1; }
+                    }
+            }
+        if (n > 0) {
+            oracle_renorm_L2((size_t)d, (size_t)n, xb);
+            (void)oracle_fvec_L2sqr(xb, xq, (size_t)d);
+            (void)oracle_fvec_inner_product(xb, xq, (size_t)d);
+        }
+        free(xb); free(xq); free(D); free(I);
+    }
+    puts("driver ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "oracle_san"
+    r = subprocess.run([gcc, "-g", "-O1", "-fopenmp", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-fno-omit-frame-pointer", os.path.join(root, "oracle", "flat_oracle.c"), str(drv), "-lm", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="3")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "driver ok" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, \
+        (r.stdout[-500:], r.stderr[-2000:])
