@@ -281,7 +281,7 @@ int main(void) {
                         "-fno-omit-frame-pointer", os.path.join(root, "oracle", "flat_oracle.c"), str(drv), "-lm", "-o", str(exe)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="3")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", OMP_NUM_THREADS="3")
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0 and "driver ok" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, \
         (r.stdout[-500:], r.stderr[-2000:])
