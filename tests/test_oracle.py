@@ -280,6 +280,8 @@ int main(void) {
     r = subprocess.run([gcc, "-g", "-O1", "-fopenmp", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                         "-fno-omit-frame-pointer", os.path.join(root, "oracle", "flat_oracle.c"), str(drv), "-lm", "-o", str(exe)],
                        capture_output=True, text=True)
+    if r.returncode != 0 and ("lasan" in r.stderr or "lubsan" in r.stderr or "libasan" in r.stderr):
+        pytest.skip("the sanitizer runtimes are not installed")
     assert r.returncode == 0, r.stderr
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", OMP_NUM_THREADS="3")
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
