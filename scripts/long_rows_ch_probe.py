@@ -1,7 +1,7 @@
 """Long rows (2048 floats: the reference's own descriptor) through the streaming kernel: per-batch time (one stream),
 L2 and inner product, nq 1 and 16, with a checksum of the results (seeded inputs)."""
 import os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_search_engine_amd.faiss_compat as faiss
 k = 20

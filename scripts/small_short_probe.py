@@ -1,7 +1,7 @@
 """Batches of 1 and 16 queries against SMALL indexes of short rows (short_scan_kernel's plan): per-batch time on one
 stream, seeded inputs, result checksums."""
 import os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import image_search_engine_amd.faiss_compat as faiss
 k = 10
